@@ -1,0 +1,226 @@
+"""ORACLE (test infrastructure, never imported by the product package).
+
+Functional plain-PyTorch restatement of the pixel-space DDPM U-Net the reference
+runs its unconditional pullback on.
+
+Follows /root/reference/src/models/ddpm/diffusion.py:
+  * architecture/table of blocks ....... :22-129  (DDPM.__init__)
+  * feature map get_h(op, block_idx) ... :202-271 (PullBackDDPM.get_h)
+  * full eps forward ................... :145-200 (PullBackDDPM.forward, u=None)
+  * sinusoid timestep embedding ........ :783-804 ([sin, cos], half_dim-1 denominator)
+  * ResnetBlock ........................ :855-912
+  * AttnBlock (single head, 1x1 convs) . :914-966
+  * Downsample (pad (0,1,0,1), s2) ..... :834-853 ; Upsample (nearest x2 + conv) :816-832
+  * GroupNorm(32, eps=1e-6) ............ :810-811
+
+It is the same architecture family as HF ``google/ddpm-ema-celebahq-256``
+(``UNet2DModel``) that ``get_h_uncond`` (src/utils/utils.py:114-163) drives.
+
+Parameters live in a flat ``dict[str, Tensor]`` whose keys equal the vendored
+module's ``state_dict()`` keys, so a reference state_dict can be fed unchanged
+(that is how tests pin this file against the reference).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass(frozen=True)
+class DDPMConfig:
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4, 4)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = (16,)
+    in_channels: int = 3
+    out_ch: int = 3
+    resolution: int = 256
+    groups: int = 32
+    gn_eps: float = 1e-6
+
+    @property
+    def temb_ch(self) -> int:
+        return self.ch * 4
+
+
+# configs/custom_celeba_ddpm.yml:21-30
+CELEBA_HQ_256 = DDPMConfig()
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusion.py:783-804 -- [sin | cos], frequencies exp(-ln(1e4) * i/(half-1))."""
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
+    ang = t.float()[:, None] * freqs[None, :]
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if dim % 2 == 1:
+        emb = F.pad(emb, (0, 1, 0, 0))
+    return emb
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _gn(p: Params, name: str, x, cfg: DDPMConfig):
+    return F.group_norm(x, cfg.groups, p[name + ".weight"], p[name + ".bias"], cfg.gn_eps)
+
+
+def _conv(p: Params, name: str, x, stride=1, padding=1):
+    return F.conv2d(x, p[name + ".weight"], p[name + ".bias"], stride=stride, padding=padding)
+
+
+def _resblock(p: Params, pre: str, x, temb, cfg: DDPMConfig):
+    h = _conv(p, pre + ".conv1", _swish(_gn(p, pre + ".norm1", x, cfg)))
+    h = h + F.linear(_swish(temb), p[pre + ".temb_proj.weight"], p[pre + ".temb_proj.bias"])[:, :, None, None]
+    h = _conv(p, pre + ".conv2", _swish(_gn(p, pre + ".norm2", h, cfg)))
+    if (pre + ".nin_shortcut.weight") in p:
+        x = _conv(p, pre + ".nin_shortcut", x, padding=0)
+    return x + h
+
+
+def _attn(p: Params, pre: str, x, cfg: DDPMConfig):
+    b, c, hh, ww = x.shape
+    n = _gn(p, pre + ".norm", x, cfg)
+    q = _conv(p, pre + ".q", n, padding=0).reshape(b, c, hh * ww).permute(0, 2, 1)   # b,hw,c
+    k = _conv(p, pre + ".k", n, padding=0).reshape(b, c, hh * ww)                    # b,c,hw
+    v = _conv(p, pre + ".v", n, padding=0).reshape(b, c, hh * ww)
+    w = torch.softmax(torch.bmm(q, k) * (int(c) ** -0.5), dim=2)                     # b,hw(q),hw(k)
+    o = torch.bmm(v, w.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + _conv(p, pre + ".proj_out", o, padding=0)
+
+
+def _down(p: Params, pre: str, x):
+    return _conv(p, pre + ".conv", F.pad(x, (0, 1, 0, 1)), stride=2, padding=0)
+
+
+def _up(p: Params, pre: str, x):
+    return _conv(p, pre + ".conv", F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+def forward(p: Params, cfg: DDPMConfig, x: torch.Tensor, t, stop: Optional[Tuple[str, int]] = None):
+    """Run the U-Net.  ``stop=(op, idx)`` returns the feature map ``get_h`` returns
+    (diffusion.py:239-242, :250-253, :266-269); ``stop=None`` returns eps."""
+    if not torch.is_tensor(t):
+        t = torch.tensor([t])
+    t = t.reshape(-1) if t.dim() else t[None]
+    temb = timestep_embedding(t, cfg.ch)
+    temb = F.linear(temb, p["temb.dense.0.weight"], p["temb.dense.0.bias"])
+    temb = F.linear(_swish(temb), p["temb.dense.1.weight"], p["temb.dense.1.bias"])
+
+    nres = len(cfg.ch_mult)
+    res = cfg.resolution
+    hs = [_conv(p, "conv_in", x)]
+    for lvl in range(nres):
+        for blk in range(cfg.num_res_blocks):
+            h = _resblock(p, f"down.{lvl}.block.{blk}", hs[-1], temb, cfg)
+            if res in cfg.attn_resolutions:
+                h = _attn(p, f"down.{lvl}.attn.{blk}", h, cfg)
+            hs.append(h)
+        if lvl != nres - 1:
+            hs.append(_down(p, f"down.{lvl}.downsample", hs[-1]))
+            res //= 2
+        if stop == ("down", lvl):
+            return hs[-1]
+
+    h = _resblock(p, "mid.block_1", hs[-1], temb, cfg)
+    h = _attn(p, "mid.attn_1", h, cfg)
+    h = _resblock(p, "mid.block_2", h, temb, cfg)
+    if stop == ("mid", 0):
+        return h
+
+    for lvl in reversed(range(nres)):
+        for blk in range(cfg.num_res_blocks + 1):
+            h = _resblock(p, f"up.{lvl}.block.{blk}", torch.cat([h, hs.pop()], dim=1), temb, cfg)
+            if res in cfg.attn_resolutions:
+                h = _attn(p, f"up.{lvl}.attn.{blk}", h, cfg)
+        if lvl != 0:
+            h = _up(p, f"up.{lvl}.upsample", h)
+            res *= 2
+        if stop == ("up", lvl):
+            return h
+    if stop is not None:
+        raise ValueError(f"(op, block_idx) = {stop} is not valid")
+    return _conv(p, "conv_out", _swish(_gn(p, "norm_out", h, cfg)))
+
+
+def param_shapes(cfg: DDPMConfig) -> Dict[str, Tuple[int, ...]]:
+    """Names/shapes of every parameter (equals the vendored module's state_dict layout)."""
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(n, i, o):
+        s[n + ".weight"] = (o, i); s[n + ".bias"] = (o,)
+
+    def conv(n, i, o, k):
+        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
+
+    def gn(n, c):
+        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
+
+    def resblock(n, i, o):
+        gn(n + ".norm1", i); conv(n + ".conv1", i, o, 3); lin(n + ".temb_proj", cfg.temb_ch, o)
+        gn(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".nin_shortcut", i, o, 1)
+
+    def attn(n, c):
+        gn(n + ".norm", c)
+        for w in ("q", "k", "v", "proj_out"):
+            conv(n + "." + w, c, c, 1)
+
+    lin("temb.dense.0", cfg.ch, cfg.temb_ch); lin("temb.dense.1", cfg.temb_ch, cfg.temb_ch)
+    conv("conv_in", cfg.in_channels, cfg.ch, 3)
+    nres = len(cfg.ch_mult)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    res = cfg.resolution
+    bi = cfg.ch
+    for lvl in range(nres):
+        bi, bo = cfg.ch * in_mult[lvl], cfg.ch * cfg.ch_mult[lvl]
+        for blk in range(cfg.num_res_blocks):
+            resblock(f"down.{lvl}.block.{blk}", bi, bo)
+            bi = bo
+            if res in cfg.attn_resolutions:
+                attn(f"down.{lvl}.attn.{blk}", bi)
+        if lvl != nres - 1:
+            conv(f"down.{lvl}.downsample.conv", bi, bi, 3)
+            res //= 2
+    resblock("mid.block_1", bi, bi); attn("mid.attn_1", bi); resblock("mid.block_2", bi, bi)
+    for lvl in reversed(range(nres)):
+        bo = cfg.ch * cfg.ch_mult[lvl]
+        skip = bo
+        for blk in range(cfg.num_res_blocks + 1):
+            if blk == cfg.num_res_blocks:
+                skip = cfg.ch * in_mult[lvl]
+            resblock(f"up.{lvl}.block.{blk}", bi + skip, bo)
+            bi = bo
+            if res in cfg.attn_resolutions:
+                attn(f"up.{lvl}.attn.{blk}", bi)
+        if lvl != 0:
+            conv(f"up.{lvl}.upsample.conv", bi, bi, 3)
+            res *= 2
+    gn("norm_out", bi); conv("conv_out", bi, cfg.out_ch, 3)
+    return s
+
+
+def init_params(cfg: DDPMConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32) -> Params:
+    """Seeded synthetic weights (no checkpoints are reachable offline).
+
+    Fan-in scaled normal for matrices, GroupNorm affine near identity.  Generated on
+    CPU so the oracle and the HIP engine see identical bits."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shp in param_shapes(cfg).items():
+        if name.endswith(".weight") and len(shp) == 1:          # norm gamma
+            p[name] = (1.0 + 0.1 * torch.randn(shp, generator=g)).to(dtype)
+        elif name.endswith(".bias"):
+            p[name] = (0.05 * torch.randn(shp, generator=g)).to(dtype)
+        else:
+            fan_in = math.prod(shp[1:])
+            p[name] = (gain * torch.randn(shp, generator=g) / math.sqrt(fan_in)).to(dtype)
+    return p

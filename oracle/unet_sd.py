@@ -1,0 +1,246 @@
+"""ORACLE (test infrastructure, never imported by the product package).
+
+PARITY UNPINNED.  Functional plain-PyTorch restatement of the latent-space
+``UNet2DConditionModel`` of Stable Diffusion v1.5 as published in
+``diffusers==0.11.0`` (third-party; pinned in /root/reference/requirements.txt:4;
+NOT vendored under /root/reference and not installed here).  The reference only
+drives that class through its sub-modules:
+
+  * src/utils/utils.py:438-527  get_h: time_proj -> time_embedding -> conv_in ->
+    down_blocks -> mid_block -> up_blocks, returning the activations at (op, idx)
+  * src/modules/edit.py:454-458 full ``unet(x, t, encoder_hidden_states=).sample``
+
+Architecture facts restated here: block_out_channels
+(320,640,1280,1280), 2 layers/block, CrossAttnDown x3 + Down, mid
+(Res, Transformer, Res), Up + CrossAttnUp x3 with skip concat and nearest x2 +
+conv3x3; 8 heads; GroupNorm(32) eps 1e-5 in ResBlocks / 1e-6 before the
+transformer; time embedding [cos | sin] of dim 320, freq exponent -ln(1e4)*i/160.
+``('down', i)`` returns the block output *after its downsampler* -- the intent of
+the reference's unreachable utils.py:489-490 (its live branch :476-480 cannot run).
+
+Parameter names equal diffusers' ``state_dict`` keys so real weights can be fed
+when present.  Anchors: parameter count 859,520,964 (tests/test_oracle.py).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass(frozen=True)
+class SDConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    down_attn: Tuple[bool, ...] = (True, True, True, False)
+    up_attn: Tuple[bool, ...] = (False, True, True, True)
+    heads: Tuple[int, ...] = (8, 8, 8, 8)          # per down block; mid uses heads[-1]
+    cross_dim: int = 768
+    groups: int = 32
+    sample_size: int = 64
+    use_linear_projection: bool = False            # SD-2.x stores proj_in/out as Linear
+    ctx_len: int = 77
+
+    @property
+    def temb_ch(self) -> int:
+        return self.block_out_channels[0] * 4
+
+
+SD15 = SDConfig()
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0): [cos | sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ang = t.float()[:, None] * freqs[None, :]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+def _gn(p, n, x, groups, eps):
+    return F.group_norm(x, groups, p[n + ".weight"], p[n + ".bias"], eps)
+
+
+def _conv(p, n, x, stride=1, padding=1):
+    return F.conv2d(x, p[n + ".weight"], p[n + ".bias"], stride=stride, padding=padding)
+
+
+def _lin(p, n, x):
+    return F.linear(x, p[n + ".weight"], p.get(n + ".bias"))
+
+
+def _resnet(p, pre, x, temb, cfg):
+    h = _conv(p, pre + ".conv1", F.silu(_gn(p, pre + ".norm1", x, cfg.groups, 1e-5)))
+    h = h + _lin(p, pre + ".time_emb_proj", F.silu(temb))[:, :, None, None]
+    h = _conv(p, pre + ".conv2", F.silu(_gn(p, pre + ".norm2", h, cfg.groups, 1e-5)))
+    if (pre + ".conv_shortcut.weight") in p:
+        x = _conv(p, pre + ".conv_shortcut", x, padding=0)
+    return x + h
+
+
+def _mha(p, pre, x, ctx, heads):
+    """CrossAttention: to_q/k/v without bias, softmax(q k^T d^-1/2) v, to_out.0 with bias."""
+    b, n, c = x.shape
+    d = c // heads
+    q = _lin(p, pre + ".to_q", x).reshape(b, n, heads, d).transpose(1, 2)
+    k = _lin(p, pre + ".to_k", ctx).reshape(b, ctx.shape[1], heads, d).transpose(1, 2)
+    v = _lin(p, pre + ".to_v", ctx).reshape(b, ctx.shape[1], heads, d).transpose(1, 2)
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(b, n, c)
+    return _lin(p, pre + ".to_out.0", o)
+
+
+def _transformer(p, pre, x, ctx, heads, cfg):
+    b, c, hh, ww = x.shape
+    h = _gn(p, pre + ".norm", x, cfg.groups, 1e-6)
+    if cfg.use_linear_projection:
+        h = _lin(p, pre + ".proj_in", h.permute(0, 2, 3, 1).reshape(b, hh * ww, c))
+    else:
+        h = _conv(p, pre + ".proj_in", h, padding=0).permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+    tb = pre + ".transformer_blocks.0"
+    ln = lambda n, z: F.layer_norm(z, (c,), p[n + ".weight"], p[n + ".bias"], 1e-5)
+    z = ln(tb + ".norm1", h)
+    h = h + _mha(p, tb + ".attn1", z, z, heads)
+    h = h + _mha(p, tb + ".attn2", ln(tb + ".norm2", h), ctx, heads)
+    f = _lin(p, tb + ".ff.net.0.proj", ln(tb + ".norm3", h))
+    a, g = f.chunk(2, dim=-1)
+    h = h + _lin(p, tb + ".ff.net.2", a * F.gelu(g))
+    if cfg.use_linear_projection:
+        h = _lin(p, pre + ".proj_out", h).reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+    else:
+        h = _conv(p, pre + ".proj_out", h.reshape(b, hh, ww, c).permute(0, 3, 1, 2), padding=0)
+    return h + x
+
+
+def forward(p: Params, cfg: SDConfig, x, t, ctx, stop: Optional[Tuple[str, int]] = None):
+    """``stop=(op, idx)`` -> feature map of get_h (utils.py:438-527); None -> eps."""
+    if not torch.is_tensor(t):
+        t = torch.tensor([float(t)])
+    t = t.reshape(-1) if t.dim() else t[None]
+    t = t.expand(x.shape[0]) if t.shape[0] != x.shape[0] else t
+    emb = timestep_embedding(t, cfg.block_out_channels[0]).to(x.dtype)
+    emb = _lin(p, "time_embedding.linear_2", F.silu(_lin(p, "time_embedding.linear_1", emb)))
+
+    h = _conv(p, "conv_in", x)
+    skips = [h]
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            h = _resnet(p, f"down_blocks.{i}.resnets.{j}", h, emb, cfg)
+            if cfg.down_attn[i]:
+                h = _transformer(p, f"down_blocks.{i}.attentions.{j}", h, ctx, cfg.heads[i], cfg)
+            skips.append(h)
+        if i != nb - 1:
+            h = _conv(p, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
+            skips.append(h)
+        if stop == ("down", i):
+            return h
+
+    h = _resnet(p, "mid_block.resnets.0", h, emb, cfg)
+    h = _transformer(p, "mid_block.attentions.0", h, ctx, cfg.heads[-1], cfg)
+    h = _resnet(p, "mid_block.resnets.1", h, emb, cfg)
+    if stop == ("mid", 0):
+        return h
+
+    rheads = tuple(reversed(cfg.heads))
+    for i in range(nb):
+        for j in range(cfg.layers_per_block + 1):
+            h = _resnet(p, f"up_blocks.{i}.resnets.{j}", torch.cat([h, skips.pop()], dim=1), emb, cfg)
+            if cfg.up_attn[i]:
+                h = _transformer(p, f"up_blocks.{i}.attentions.{j}", h, ctx, rheads[i], cfg)
+        if i != nb - 1:
+            h = _conv(p, f"up_blocks.{i}.upsamplers.0.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+        if stop == ("up", i):
+            return h
+    if stop is not None:
+        raise ValueError(f"(op, block_idx) = {stop} is not valid")
+    return _conv(p, "conv_out", F.silu(_gn(p, "conv_norm_out", h, cfg.groups, 1e-5)))
+
+
+def param_shapes(cfg: SDConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(n, i, o, bias=True):
+        s[n + ".weight"] = (o, i)
+        if bias:
+            s[n + ".bias"] = (o,)
+
+    def conv(n, i, o, k):
+        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
+
+    def norm(n, c):
+        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
+
+    def resnet(n, i, o):
+        norm(n + ".norm1", i); conv(n + ".conv1", i, o, 3); lin(n + ".time_emb_proj", cfg.temb_ch, o)
+        norm(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1)
+
+    def attn(n, c, kv):
+        lin(n + ".to_q", c, c, False); lin(n + ".to_k", kv, c, False); lin(n + ".to_v", kv, c, False)
+        lin(n + ".to_out.0", c, c)
+
+    def transformer(n, c):
+        norm(n + ".norm", c)
+        if cfg.use_linear_projection:
+            lin(n + ".proj_in", c, c); lin(n + ".proj_out", c, c)
+        else:
+            conv(n + ".proj_in", c, c, 1); conv(n + ".proj_out", c, c, 1)
+        tb = n + ".transformer_blocks.0"
+        norm(tb + ".norm1", c); attn(tb + ".attn1", c, c)
+        norm(tb + ".norm2", c); attn(tb + ".attn2", c, cfg.cross_dim)
+        norm(tb + ".norm3", c); lin(tb + ".ff.net.0.proj", c, 8 * c); lin(tb + ".ff.net.2", 4 * c, c)
+
+    boc = cfg.block_out_channels
+    nb = len(boc)
+    lin("time_embedding.linear_1", boc[0], cfg.temb_ch); lin("time_embedding.linear_2", cfg.temb_ch, cfg.temb_ch)
+    conv("conv_in", cfg.in_channels, boc[0], 3)
+    ch = boc[0]
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{i}.resnets.{j}", ch, boc[i]); ch = boc[i]
+            if cfg.down_attn[i]:
+                transformer(f"down_blocks.{i}.attentions.{j}", ch)
+        if i != nb - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", ch, ch, 3)
+    resnet("mid_block.resnets.0", ch, ch); transformer("mid_block.attentions.0", ch); resnet("mid_block.resnets.1", ch, ch)
+    rev = tuple(reversed(boc))
+    prev = rev[0]
+    for i in range(nb):
+        out = rev[i]
+        inp = rev[min(i + 1, nb - 1)]
+        for j in range(cfg.layers_per_block + 1):
+            skip = inp if j == cfg.layers_per_block else out
+            rin = prev if j == 0 else out
+            resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, out)
+            if cfg.up_attn[i]:
+                transformer(f"up_blocks.{i}.attentions.{j}", out)
+        if i != nb - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", out, out, 3)
+        prev = out
+    norm("conv_norm_out", boc[0]); conv("conv_out", boc[0], cfg.out_channels, 3)
+    return s
+
+
+def init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32, only_prefix=None) -> Params:
+    """Seeded synthetic weights at the exact architecture shapes (CPU generator)."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shp in param_shapes(cfg).items():
+        if name.endswith(".weight") and len(shp) == 1:
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g)
+        else:
+            t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
+        if only_prefix is None or name.startswith(only_prefix):
+            p[name] = t.to(dtype)
+    return p
