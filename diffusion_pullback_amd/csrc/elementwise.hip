@@ -1,0 +1,272 @@
+// HBM-bound elementwise kernels: GEGLU (primal/tangent/adjoint), SiLU, accumulate, channel-window copies,
+// NCHW<->NHWC boundary transposes, 2x2 sum pooling (adjoint of nearest upsampling), DDIM step.
+// All use 16-byte chunks per lane and grid-stride loops.
+#include "kernels.h"
+
+namespace dpb {
+
+static inline unsigned grid_for(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void geglu_kernel(GegluArgs a, long nrows) {
+  constexpr int CH = TT<T>::CH;
+  const int fch = a.F / CH;
+  const long total = nrows * fch;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long row = idx / fch;
+    const int c = (int)(idx - row * fch) * CH;
+    long prow = row;
+    if (MODE != MODE_PRIMAL) {
+      long j = row / a.rows_per_sample, l = row - j * a.rows_per_sample;
+      prow = (j / a.kps) * a.rows_per_sample + l;
+    }
+    const T* hp = (const T*)a.h + prow * 2 * a.F;
+    float av[CH], gv[CH], o[CH];
+    Vec<T>::load(hp + c, av);
+    Vec<T>::load(hp + a.F + c, gv);
+    if (MODE == MODE_PRIMAL) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) o[e] = av[e] * gelu_(gv[e]);
+      Vec<T>::store((T*)a.y + row * a.F + c, o);
+    } else if (MODE == MODE_TANGENT) {
+      const T* dp = (const T*)a.d + row * 2 * a.F;
+      float da[CH], dg[CH];
+      Vec<T>::load(dp + c, da);
+      Vec<T>::load(dp + a.F + c, dg);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) o[e] = da[e] * gelu_(gv[e]) + av[e] * dgelu_(gv[e]) * dg[e];
+      Vec<T>::store((T*)a.y + row * a.F + c, o);
+    } else {
+      float gy[CH], o2[CH];
+      Vec<T>::load((const T*)a.d + row * a.F + c, gy);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        o[e] = gy[e] * gelu_(gv[e]);
+        o2[e] = gy[e] * av[e] * dgelu_(gv[e]);
+      }
+      T* yp = (T*)a.y + row * 2 * a.F;
+      if (a.accumulate) {
+        float t1[CH], t2[CH];
+        Vec<T>::load(yp + c, t1);
+        Vec<T>::load(yp + a.F + c, t2);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { o[e] += t1[e]; o2[e] += t2[e]; }
+      }
+      Vec<T>::store(yp + c, o);
+      Vec<T>::store(yp + a.F + c, o2);
+    }
+  }
+}
+
+template <typename T>
+static int geglu_t(int mode, const GegluArgs& a, hipStream_t st) {
+  if (a.F % TT<T>::CH) { set_error("geglu: F=%d not chunk aligned", a.F); return -1; }
+  long nrows = (long)(mode == MODE_PRIMAL ? a.Bp : a.NT) * a.rows_per_sample;
+  unsigned g = grid_for(nrows * (a.F / TT<T>::CH));
+  if (mode == MODE_PRIMAL) hipLaunchKernelGGL((geglu_kernel<T, MODE_PRIMAL>), dim3(g), dim3(256), 0, st, a, nrows);
+  else if (mode == MODE_TANGENT) hipLaunchKernelGGL((geglu_kernel<T, MODE_TANGENT>), dim3(g), dim3(256), 0, st, a, nrows);
+  else hipLaunchKernelGGL((geglu_kernel<T, MODE_ADJOINT>), dim3(g), dim3(256), 0, st, a, nrows);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st) {
+  return dtype == DT_F32 ? geglu_t<float>(mode, a, st) : geglu_t<bf16>(mode, a, st);
+}
+
+template <typename T, int OP>   // 0: silu  1: y = x  2: y += x
+__global__ __launch_bounds__(256) void unary_kernel(const T* x, T* y, long nchunks) {
+  constexpr int CH = TT<T>::CH;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+    float v[CH];
+    Vec<T>::load(x + i * CH, v);
+    if (OP == 0) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] = silu_(v[e]);
+    } else if (OP == 2) {
+      float o[CH];
+      Vec<T>::load(y + i * CH, o);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += o[e];
+    }
+    Vec<T>::store(y + i * CH, v);
+  }
+}
+
+template <typename T>
+static int unary_t(int op, const void* x, void* y, long n, hipStream_t st) {
+  if (n % TT<T>::CH) { set_error("elementwise: n=%ld not chunk aligned", n); return -1; }
+  long nc = n / TT<T>::CH;
+  unsigned g = grid_for(nc);
+  if (op == 0) hipLaunchKernelGGL((unary_kernel<T, 0>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
+  else if (op == 1) hipLaunchKernelGGL((unary_kernel<T, 1>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
+  else hipLaunchKernelGGL((unary_kernel<T, 2>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st) {
+  return dtype == DT_F32 ? unary_t<float>(0, x, y, n, st) : unary_t<bf16>(0, x, y, n, st);
+}
+int launch_axpy(int dtype, const void* x, void* y, long n, int accumulate, hipStream_t st) {
+  int op = accumulate ? 2 : 1;
+  return dtype == DT_F32 ? unary_t<float>(op, x, y, n, st) : unary_t<bf16>(op, x, y, n, st);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const T* src, int lds_, int cs0, T* dst, int ldd, int cd0, long rows,
+                                                        int ncols, int accumulate) {
+  constexpr int CH = TT<T>::CH;
+  const int nch = ncols / CH;
+  const long total = rows * nch;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / nch;
+    const int c = (int)(idx - r * nch) * CH;
+    float v[CH];
+    Vec<T>::load(src + r * lds_ + cs0 + c, v);
+    T* dp = dst + r * ldd + cd0 + c;
+    if (accumulate) {
+      float o[CH];
+      Vec<T>::load(dp, o);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += o[e];
+    }
+    Vec<T>::store(dp, v);
+  }
+}
+int launch_copy_cols(int dtype, const void* src, int lds_, int cs0, void* dst, int ldd, int cd0, long rows, int ncols, int accumulate,
+                     hipStream_t st) {
+  int CH = dtype == DT_F32 ? 4 : 8;
+  if (ncols % CH || cs0 % CH || cd0 % CH || lds_ % CH || ldd % CH) { set_error("copy_cols: misaligned window"); return -1; }
+  unsigned g = grid_for(rows * (ncols / CH));
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((copy_cols_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, lds_, cs0, (float*)dst, ldd, cd0, rows, ncols, accumulate);
+  else
+    hipLaunchKernelGGL((copy_cols_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)src, lds_, cs0, (bf16*)dst, ldd, cd0, rows, ncols, accumulate);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+// fp32 NCHW -> T NHWC (channel pad to Cpad with zeros).  Small tensors (boundary only): tile transpose through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int C, int HW, int Cpad) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {   // k: channel, tx: pixel (contiguous in src)
+    int c = c0 + k, p = p0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? src[((long)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {   // k: pixel, tx: channel (contiguous in dst)
+    int p = p0 + k, c = c0 + tx;
+    if (p < HW && c < Cpad) TT<T>::st(dst + ((long)n * HW + p) * Cpad + c, tile[tx][k]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* dst, int C, int HW, int Cpad) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {   // k: pixel, tx: channel
+    int p = p0 + k, c = c0 + tx;
+    tile[k][tx] = (p < HW && c < C) ? TT<T>::ld(src + ((long)n * HW + p) * Cpad + c) : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {   // k: channel, tx: pixel
+    int c = c0 + k, p = p0 + tx;
+    if (c < C && p < HW) dst[((long)n * C + c) * HW + p] = tile[tx][k];
+  }
+}
+int launch_nchw_to_nhwc(int dtype, const float* src, void* dst, int n, int C, int HW, int Cpad, hipStream_t st) {
+  dim3 grid((HW + 31) / 32, (Cpad + 31) / 32, n);
+  if (dtype == DT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), 0, st, src, (float*)dst, C, HW, Cpad);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16>), grid, dim3(256), 0, st, src, (bf16*)dst, C, HW, Cpad);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_nhwc_to_nchw(int dtype, const void* src, float* dst, int n, int C, int HW, int Cpad, hipStream_t st) {
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, n);
+  if (dtype == DT_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), grid, dim3(256), 0, st, (const float*)src, dst, C, HW, Cpad);
+  else hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, dst, C, HW, Cpad);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const T* in, T* out, int n, int H, int W, int C, int accumulate) {
+  constexpr int CH = TT<T>::CH;
+  const int cch = C / CH;
+  const long total = (long)n * H * W * cch;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % cch) * CH;
+    long pix = idx / cch;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    const long s = pix / H;
+    float acc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float v[CH];
+        Vec<T>::load(in + ((s * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] += v[e];
+      }
+    T* op = out + ((s * H + y) * W + x) * C + c;
+    if (accumulate) {
+      float o[CH];
+      Vec<T>::load(op, o);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc[e] += o[e];
+    }
+    Vec<T>::store(op, acc);
+  }
+}
+int launch_pool2x2_sum(int dtype, const void* in, void* out, int n, int H, int W, int C, int accumulate, hipStream_t st) {
+  int CH = dtype == DT_F32 ? 4 : 8;
+  unsigned g = grid_for((long)n * H * W * (C / CH));
+  if (dtype == DT_F32) hipLaunchKernelGGL((pool2x2_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)in, (float*)out, n, H, W, C, accumulate);
+  else hipLaunchKernelGGL((pool2x2_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)in, (bf16*)out, n, H, W, C, accumulate);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void ddim_kernel(const float* x, const float* e, float* out, float* x0, long n, float sa, float s1a,
+                                                   float san, float s1an) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float p = (x[i] - e[i] * s1a) / sa;
+    if (x0) x0[i] = p;
+    out[i] = san * p + s1an * e[i];
+  }
+}
+int launch_ddim_step(const float* x, const float* e, float* out, float* x0, long n, float a_t, float a_next, hipStream_t st) {
+  // same operation order as the reference (utils.py:301-306): sqrt in fp32 of the fp32 alphas
+  hipLaunchKernelGGL(ddim_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, e, out, x0, n, sqrtf(a_t), sqrtf(1.f - a_t), sqrtf(a_next),
+                     sqrtf(1.f - a_next));
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void lincomb_kernel(const float* x, const float* y, const float* z, float* out, long n, float a, float b,
+                                                      float c) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = a * x[i] + b * y[i];
+    if (z) v += c * z[i];
+    out[i] = v;
+  }
+}
+int launch_lincomb(const float* x, const float* y, const float* z, float* out, long n, float a, float b, float c, hipStream_t st) {
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, z, out, n, a, b, c);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dpb

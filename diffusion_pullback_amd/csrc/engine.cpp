@@ -1,0 +1,755 @@
+// Tape executor + C ABI (include/dpb.h) of the MI355X pullback engine.
+//
+// A network is a tape of NHWC ops over numbered activation buffers.  Three passes run over a
+// prefix of the tape:
+//   primal  : batch B, keeps EVERY activation, GroupNorm statistic and attention matrix resident
+//             in HBM (288 GB/GPU makes recomputation pointless).  x_t and t are fixed during a
+//             power iteration, so this pass runs once per sample, not once per JVP/VJP as the
+//             reference's autodiff does (src/utils/utils.py:766-797).
+//   tangent : nt = B*k tangents pushed forward through the same kernels (linear ops: identical
+//             GEMM with M scaled by k; nonlinear ops: closed-form tangent using the primal stash).
+//   adjoint : nt cotangents pulled back in reverse tape order, input gradients only (no weight
+//             gradients), fan-in handled by first-write/accumulate flags per buffer.
+// Ops whose inputs do not depend on x (time-embedding MLP, text-conditioning K/V projections)
+// are primal-only.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dpb.h"
+#include "kernels.h"
+
+namespace dpb {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+static inline int round8(int v) { return (v + 7) / 8 * 8; }
+
+struct Buf {
+  int rows = 0, C = 0, kind = 0;
+  bool is_const = true;      // independent of x
+  size_t p_off = 0, t_off = 0, g_off = 0;
+};
+
+struct AttnPlan {            // per attention op, persisted from the primal pass
+  int heads = 0, d = 0, Lq = 0, Lk = 0, Lqp = 0, Lkp = 0;
+  bool kv_const = false;
+  size_t P = 0, PT = 0, KT = 0, VT = 0, QT = 0;   // offsets
+};
+
+struct Op {
+  dpb_op_desc d;
+  bool is_const = true;
+  int attn = -1;             // index into plans
+  size_t pstats = 0, tstats = 0;   // GroupNorm stat slots (offsets)
+};
+
+}  // namespace dpb
+
+using namespace dpb;
+
+struct dpb_engine {
+  int dtype = DT_F32, es = 4;
+  int maxB = 1, maxT = 1;
+  std::vector<Buf> bufs;
+  std::vector<Op> ops;
+  std::vector<AttnPlan> plans;
+  std::vector<int> producer;        // buffer -> op index producing it (-1 for inputs)
+  int x_buf = -1, x_channels = 0, temb_buf = -1, temb_dim = 0, temb_flip = 0, temb_hm1 = 0, ctx_buf = -1;
+  hipStream_t stream = 0;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  // arena offsets
+  size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0;
+  size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0;
+  size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
+  size_t temb_host_stage = 0;
+  int cur_batch = 0;
+  std::vector<char> ginit;
+  long n_launch = 0;
+  double flops = 0, gbytes = 0;
+
+  char* P(int b) const { return ws + bufs[b].p_off; }
+  char* T(int b) const { return ws + bufs[b].t_off; }
+  char* G(int b) const { return ws + bufs[b].g_off; }
+};
+
+namespace {
+
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+int gemm(dpb_engine* e, const GemmArgs& a) {
+  e->n_launch++;
+  e->flops += 2.0 * a.M * (double)a.N * a.K * a.Z1 * a.Z2;
+  e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
+  return launch_gemm(e->dtype, a, e->stream);
+}
+
+// ------------------------------------------------------------------ CONV
+// mode 0 primal (n=B), 1 tangent (n=nt)
+int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
+  const dpb_op_desc& d = op.d;
+  const int H = d.ip[0], W = d.ip[1], Cin = d.ip[2], Ho = d.ip[3], Wo = d.ip[4], Cout = d.ip[5], KS = d.ip[6];
+  const Buf& bi = e->bufs[d.in0];
+  const Buf& bo = e->bufs[d.out];
+  if (mode == 1 && bi.is_const) {     // only the residual carries a tangent
+    e->n_launch++;
+    return launch_axpy(e->dtype, e->T(d.res), e->T(d.out), (long)n * bo.rows * bo.C, 0, e->stream);
+  }
+  GemmArgs g;
+  const bool shared_out = bo.kind == DPB_BUF_SHARED;
+  const int ns = shared_out ? 1 : n;
+  g.A = mode == 0 ? e->P(d.in0) : e->T(d.in0);
+  g.B = d.w[0];
+  g.C = mode == 0 ? e->P(d.out) : e->T(d.out);
+  g.N = Cout;
+  g.K = KS * KS * Cin;
+  g.ldb = g.K;
+  g.ldc = bo.C;
+  g.lda = bi.C;
+  g.gather = d.ip[9];
+  if (g.gather == GATHER_NONE) {
+    g.M = ns * bi.rows;
+  } else {
+    g.M = ns * Ho * Wo;
+    g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.KS = KS; g.stride = d.ip[7]; g.pad = d.ip[8];
+  }
+  if (mode == 0) {
+    g.bias = (const float*)d.w[2];
+    if (d.rowbias >= 0) {
+      g.rowbias = e->P(d.rowbias);
+      g.rows_per_sample = bo.rows;
+      g.rowbias_div = 1 << 30;
+    }
+  }
+  if (d.res >= 0 && (mode == 0 || !e->bufs[d.res].is_const)) {
+    g.R = mode == 0 ? e->P(d.res) : e->T(d.res);
+    g.ldr = e->bufs[d.res].C;
+  }
+  return gemm(e, g);
+}
+
+int conv_adj(dpb_engine* e, const Op& op, int n) {
+  const dpb_op_desc& d = op.d;
+  const int H = d.ip[0], W = d.ip[1], Cin = d.ip[2], Ho = d.ip[3], Wo = d.ip[4], KS = d.ip[6];
+  const Buf& bi = e->bufs[d.in0];
+  const Buf& bo = e->bufs[d.out];
+  const int Cout = bo.C;              // padded channel count of the cotangent (w[1] is [Cin][KS*KS*CoutPadded])
+  if (!bi.is_const) {
+    if (!d.w[1]) return fail("conv op has no transposed weight (w[1]) but its adjoint is needed");
+    GemmArgs g;
+    g.A = e->G(d.out);
+    g.lda = bo.C;
+    g.B = d.w[1];
+    g.N = Cin;
+    g.K = KS * KS * Cout;
+    g.ldb = g.K;
+    g.ldc = bi.C;
+    const int gather = d.ip[9];
+    if (gather == GATHER_NONE) {
+      g.M = n * bi.rows;
+      g.C = e->G(d.in0);
+      g.accumulate = e->ginit[d.in0];
+      if (int r = gemm(e, g)) return r;
+    } else if (gather == GATHER_CONV) {
+      g.gather = GATHER_CONVT;
+      g.M = n * H * W;
+      g.H = Ho; g.W = Wo; g.Cin = Cout; g.Ho = H; g.Wo = W; g.KS = KS; g.stride = d.ip[7]; g.pad = d.ip[8];
+      g.C = e->G(d.in0);
+      g.accumulate = e->ginit[d.in0];
+      if (int r = gemm(e, g)) return r;
+    } else {   // UPCONV: adjoint conv at the upsampled resolution, then 2x2 sum pooling
+      g.gather = GATHER_CONVT;
+      g.M = n * Ho * Wo;
+      g.H = Ho; g.W = Wo; g.Cin = Cout; g.Ho = Ho; g.Wo = Wo; g.KS = KS; g.stride = 1; g.pad = 1;
+      g.C = e->ws + e->convtmp;
+      if (int r = gemm(e, g)) return r;
+      e->n_launch++;
+      if (int r = launch_pool2x2_sum(e->dtype, e->ws + e->convtmp, e->G(d.in0), n, H, W, bi.C, e->ginit[d.in0], e->stream)) return r;
+    }
+    e->ginit[d.in0] = 1;
+  }
+  if (d.res >= 0 && !e->bufs[d.res].is_const) {
+    e->n_launch++;
+    if (int r = launch_axpy(e->dtype, e->G(d.out), e->G(d.res), (long)n * bo.rows * bo.C, e->ginit[d.res], e->stream)) return r;
+    e->ginit[d.res] = 1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ norms / elementwise
+int gn_run(dpb_engine* e, const Op& op, int mode, int n) {
+  const dpb_op_desc& d = op.d;
+  const Buf& bi = e->bufs[d.in0];
+  GNArgs a;
+  a.x = e->P(d.in0);
+  a.gamma = (const float*)d.w[0];
+  a.beta = (const float*)d.w[1];
+  a.pstats = (double*)(e->ws + op.pstats);
+  a.tstats = (double*)(e->ws + op.tstats);
+  a.HW = bi.rows; a.C = bi.C; a.G = d.ip[0]; a.silu = d.ip[1]; a.eps = d.fp[0];
+  a.Bp = e->cur_batch;
+  if (mode == MODE_PRIMAL) {
+    a.Bp = n;
+    a.y = e->P(d.out);
+  } else {
+    a.NT = n;
+    a.kps = n / e->cur_batch;
+    if (mode == MODE_TANGENT) {
+      a.d = e->T(d.in0);
+      a.y = e->T(d.out);
+    } else {
+      a.d = e->G(d.out);
+      a.y = e->G(d.in0);
+      a.accumulate = e->ginit[d.in0];
+      e->ginit[d.in0] = 1;
+    }
+  }
+  e->n_launch += 2;
+  return launch_groupnorm(e->dtype, mode, a, e->stream);
+}
+
+int ln_run(dpb_engine* e, const Op& op, int mode, int n) {
+  const dpb_op_desc& d = op.d;
+  const Buf& bi = e->bufs[d.in0];
+  LNArgs a;
+  a.x = e->P(d.in0);
+  a.gamma = (const float*)d.w[0];
+  a.beta = (const float*)d.w[1];
+  a.rows_per_sample = bi.rows; a.C = bi.C; a.eps = d.fp[0];
+  a.Bp = e->cur_batch;
+  if (mode == MODE_PRIMAL) {
+    a.Bp = n;
+    a.y = e->P(d.out);
+  } else {
+    a.NT = n;
+    a.kps = n / e->cur_batch;
+    if (mode == MODE_TANGENT) {
+      a.d = e->T(d.in0);
+      a.y = e->T(d.out);
+    } else {
+      a.d = e->G(d.out);
+      a.y = e->G(d.in0);
+      a.accumulate = e->ginit[d.in0];
+      e->ginit[d.in0] = 1;
+    }
+  }
+  e->n_launch++;
+  return launch_layernorm(e->dtype, mode, a, e->stream);
+}
+
+int geglu_run(dpb_engine* e, const Op& op, int mode, int n) {
+  const dpb_op_desc& d = op.d;
+  const Buf& bi = e->bufs[d.in0];
+  GegluArgs a;
+  a.h = e->P(d.in0);
+  a.rows_per_sample = bi.rows; a.F = bi.C / 2;
+  a.Bp = e->cur_batch;
+  if (mode == MODE_PRIMAL) {
+    a.Bp = n;
+    a.y = e->P(d.out);
+  } else {
+    a.NT = n;
+    a.kps = n / e->cur_batch;
+    if (mode == MODE_TANGENT) {
+      a.d = e->T(d.in0);
+      a.y = e->T(d.out);
+    } else {
+      a.d = e->G(d.out);
+      a.y = e->G(d.in0);
+      a.accumulate = e->ginit[d.in0];
+      e->ginit[d.in0] = 1;
+    }
+  }
+  e->n_launch++;
+  return launch_geglu(e->dtype, mode, a, e->stream);
+}
+
+int concat_run(dpb_engine* e, const Op& op, int mode, int n) {
+  const dpb_op_desc& d = op.d;
+  const Buf& b0 = e->bufs[d.in0];
+  const Buf& b1 = e->bufs[d.in1];
+  const Buf& bo = e->bufs[d.out];
+  const long rows = (long)n * bo.rows;
+  e->n_launch += 2;
+  if (mode == MODE_ADJOINT) {
+    if (!b0.is_const) {
+      if (int r = launch_copy_cols(e->dtype, e->G(d.out), bo.C, 0, e->G(d.in0), b0.C, 0, rows, b0.C, e->ginit[d.in0], e->stream)) return r;
+      e->ginit[d.in0] = 1;
+    }
+    if (!b1.is_const) {
+      if (int r = launch_copy_cols(e->dtype, e->G(d.out), bo.C, b0.C, e->G(d.in1), b1.C, 0, rows, b1.C, e->ginit[d.in1], e->stream)) return r;
+      e->ginit[d.in1] = 1;
+    }
+    return 0;
+  }
+  if (mode == MODE_TANGENT && (b0.is_const || b1.is_const)) return fail("concat of x-independent and x-dependent buffers is unsupported");
+  char* o = mode == MODE_PRIMAL ? e->P(d.out) : e->T(d.out);
+  const char* i0 = mode == MODE_PRIMAL ? e->P(d.in0) : e->T(d.in0);
+  const char* i1 = mode == MODE_PRIMAL ? e->P(d.in1) : e->T(d.in1);
+  if (int r = launch_copy_cols(e->dtype, i0, b0.C, 0, o, bo.C, 0, rows, b0.C, 0, e->stream)) return r;
+  return launch_copy_cols(e->dtype, i1, b1.C, 0, o, bo.C, b0.C, rows, b1.C, 0, e->stream);
+}
+
+// ------------------------------------------------------------------ attention (materialised scores)
+int attn_primal(dpb_engine* e, const Op& op, int B) {
+  const dpb_op_desc& d = op.d;
+  const AttnPlan& p = e->plans[op.attn];
+  const int C = p.heads * p.d, H = p.heads;
+  const float scale = 1.f / sqrtf((float)p.d);
+  char* ws = e->ws;
+  GemmArgs g;   // S = scale * Q K^T
+  g.A = e->P(d.in0); g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
+  g.B = e->P(d.in1); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d;
+  g.C = ws + p.P; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
+  g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = B; g.Z2 = H; g.alpha = scale;
+  if (int r = gemm(e, g)) return r;
+  e->n_launch += 3;
+  if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
+  // V^T, K^T per head ([d][Lkp], zero padded)
+  if (int r = launch_transpose(e->dtype, e->P(d.in2), ws + p.VT, B, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+  if (int r = launch_transpose(e->dtype, e->P(d.in1), ws + p.KT, B, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+  GemmArgs o;   // O = P V
+  o.A = ws + p.P; o.lda = p.Lkp; o.sA1 = (long)H * p.Lq * p.Lkp; o.sA2 = (long)p.Lq * p.Lkp;
+  o.B = ws + p.VT; o.ldb = p.Lkp; o.sB1 = (long)H * p.d * p.Lkp; o.sB2 = (long)p.d * p.Lkp;
+  o.C = e->P(d.out); o.ldc = C; o.sC1 = (long)p.Lq * C; o.sC2 = p.d;
+  o.M = p.Lq; o.N = p.d; o.K = p.Lkp; o.Z1 = B; o.Z2 = H;
+  if (int r = gemm(e, o)) return r;
+  if (!p.kv_const) {
+    e->n_launch += 2;
+    if (int r = launch_transpose(e->dtype, ws + p.P, ws + p.PT, B * H, 1, (long)p.Lq * p.Lkp, 0, p.Lq, p.Lk, p.Lkp, p.Lqp, (long)p.Lk * p.Lqp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, e->P(d.in0), ws + p.QT, B, H, (long)p.Lq * C, p.d, p.Lq, p.d, C, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+  }
+  return 0;
+}
+
+int attn_tangent(dpb_engine* e, const Op& op, int nt) {
+  const dpb_op_desc& d = op.d;
+  const AttnPlan& p = e->plans[op.attn];
+  const int C = p.heads * p.d, H = p.heads, kps = nt / e->cur_batch;
+  const float scale = 1.f / sqrtf((float)p.d);
+  char* ws = e->ws;
+  char* S1 = ws + e->S1;
+  GemmArgs g;   // dS = scale * dQ K^T
+  g.A = e->T(d.in0); g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
+  g.B = e->P(d.in1); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
+  g.C = S1; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
+  g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = nt; g.Z2 = H; g.alpha = scale;
+  if (int r = gemm(e, g)) return r;
+  if (!p.kv_const) {   // += scale * Q dK^T
+    g.A = e->P(d.in0); g.divA = kps;
+    g.B = e->T(d.in1); g.divB = 1;
+    g.accumulate = 1;
+    if (int r = gemm(e, g)) return r;
+  }
+  e->n_launch++;
+  if (int r = launch_softmax_jvp(e->dtype, ws + p.P, S1, nullptr, (long)nt * H, H, kps, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
+  GemmArgs o;   // dO = dP V
+  o.A = S1; o.lda = p.Lkp; o.sA1 = (long)H * p.Lq * p.Lkp; o.sA2 = (long)p.Lq * p.Lkp;
+  o.B = ws + p.VT; o.ldb = p.Lkp; o.sB1 = (long)H * p.d * p.Lkp; o.sB2 = (long)p.d * p.Lkp; o.divB = kps;
+  o.C = e->T(d.out); o.ldc = C; o.sC1 = (long)p.Lq * C; o.sC2 = p.d;
+  o.M = p.Lq; o.N = p.d; o.K = p.Lkp; o.Z1 = nt; o.Z2 = H;
+  if (int r = gemm(e, o)) return r;
+  if (!p.kv_const) {   // += P dV
+    char* T1 = ws + e->T1;
+    e->n_launch++;
+    if (int r = launch_transpose(e->dtype, e->T(d.in2), T1, nt, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    o.A = ws + p.P; o.divA = kps;
+    o.B = T1; o.divB = 1;
+    o.accumulate = 1;
+    if (int r = gemm(e, o)) return r;
+  }
+  return 0;
+}
+
+int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
+  const dpb_op_desc& d = op.d;
+  const AttnPlan& p = e->plans[op.attn];
+  const int C = p.heads * p.d, H = p.heads, kps = nt / e->cur_batch;
+  const float scale = 1.f / sqrtf((float)p.d);
+  char* ws = e->ws;
+  char* S1 = ws + e->S1;
+  float* Dv = (float*)(ws + e->Dv);
+  const char* gO = e->G(d.out);
+  GemmArgs g;   // gP = gO V^T
+  g.A = gO; g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
+  g.B = e->P(d.in2); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
+  g.C = S1; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
+  g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = nt; g.Z2 = H;
+  if (int r = gemm(e, g)) return r;
+  e->n_launch++;
+  if (int r = launch_softmax_jvp(e->dtype, ws + p.P, S1, p.kv_const ? nullptr : Dv, (long)nt * H, H, kps, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
+  GemmArgs q;   // gQ (+)= scale * gS K
+  q.A = S1; q.lda = p.Lkp; q.sA1 = (long)H * p.Lq * p.Lkp; q.sA2 = (long)p.Lq * p.Lkp;
+  q.B = ws + p.KT; q.ldb = p.Lkp; q.sB1 = (long)H * p.d * p.Lkp; q.sB2 = (long)p.d * p.Lkp; q.divB = kps;
+  q.C = e->G(d.in0); q.ldc = C; q.sC1 = (long)p.Lq * C; q.sC2 = p.d;
+  q.M = p.Lq; q.N = p.d; q.K = p.Lkp; q.Z1 = nt; q.Z2 = H; q.alpha = scale;
+  q.accumulate = e->ginit[d.in0];
+  if (int r = gemm(e, q)) return r;
+  e->ginit[d.in0] = 1;
+  if (p.kv_const) return 0;
+  char* T1 = ws + e->T1;
+  char* S2 = ws + e->S2;
+  e->n_launch += 2;
+  // gO^T per head [d][Lqp]
+  if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * C, p.d, p.Lq, p.d, C, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+  GemmArgs v;   // gV (+)= P^T gO
+  v.A = ws + p.PT; v.lda = p.Lqp; v.sA1 = (long)H * p.Lk * p.Lqp; v.sA2 = (long)p.Lk * p.Lqp; v.divA = kps;
+  v.B = T1; v.ldb = p.Lqp; v.sB1 = (long)H * p.d * p.Lqp; v.sB2 = (long)p.d * p.Lqp;
+  v.C = e->G(d.in2); v.ldc = C; v.sC1 = (long)p.Lk * C; v.sC2 = p.d;
+  v.M = p.Lk; v.N = p.d; v.K = p.Lqp; v.Z1 = nt; v.Z2 = H;
+  v.accumulate = e->ginit[d.in2];
+  if (int r = gemm(e, v)) return r;
+  e->ginit[d.in2] = 1;
+  GemmArgs t;   // gP^T = V gO^T
+  t.A = e->P(d.in2); t.lda = C; t.sA1 = (long)p.Lk * C; t.sA2 = p.d; t.divA = kps;
+  t.B = gO; t.ldb = C; t.sB1 = (long)p.Lq * C; t.sB2 = p.d;
+  t.C = S2; t.ldc = p.Lqp; t.sC1 = (long)H * p.Lk * p.Lqp; t.sC2 = (long)p.Lk * p.Lqp;
+  t.M = p.Lk; t.N = p.Lq; t.K = p.d; t.Z1 = nt; t.Z2 = H;
+  if (int r = gemm(e, t)) return r;
+  if (int r = launch_softmax_adjT(e->dtype, ws + p.PT, S2, Dv, (long)nt * H, H, kps, p.Lk, p.Lq, p.Lqp, e->stream)) return r;
+  GemmArgs k;   // gK (+)= scale * gS^T Q
+  k.A = S2; k.lda = p.Lqp; k.sA1 = (long)H * p.Lk * p.Lqp; k.sA2 = (long)p.Lk * p.Lqp;
+  k.B = ws + p.QT; k.ldb = p.Lqp; k.sB1 = (long)H * p.d * p.Lqp; k.sB2 = (long)p.d * p.Lqp; k.divB = kps;
+  k.C = e->G(d.in1); k.ldc = C; k.sC1 = (long)p.Lk * C; k.sC2 = p.d;
+  k.M = p.Lk; k.N = p.d; k.K = p.Lqp; k.Z1 = nt; k.Z2 = H; k.alpha = scale;
+  k.accumulate = e->ginit[d.in1];
+  if (int r = gemm(e, k)) return r;
+  e->ginit[d.in1] = 1;
+  return 0;
+}
+
+int run_op(dpb_engine* e, const Op& op, int mode, int n) {
+  switch (op.d.kind) {
+    case DPB_OP_CONV: return mode == MODE_ADJOINT ? conv_adj(e, op, n) : conv_fwd(e, op, mode, n);
+    case DPB_OP_GROUPNORM: return gn_run(e, op, mode, n);
+    case DPB_OP_LAYERNORM: return ln_run(e, op, mode, n);
+    case DPB_OP_GEGLU: return geglu_run(e, op, mode, n);
+    case DPB_OP_CONCAT: return concat_run(e, op, mode, n);
+    case DPB_OP_ATTENTION:
+      return mode == MODE_PRIMAL ? attn_primal(e, op, n) : mode == MODE_TANGENT ? attn_tangent(e, op, n) : attn_adjoint(e, op, n);
+    case DPB_OP_SILU: {
+      if (mode != MODE_PRIMAL) return fail("SILU op is only supported on the x-independent (time embedding) path");
+      const Buf& b = e->bufs[op.d.in0];
+      e->n_launch++;
+      return launch_silu(e->dtype, e->P(op.d.in0), e->P(op.d.out), (long)(b.kind == DPB_BUF_SHARED ? 1 : n) * b.rows * b.C, e->stream);
+    }
+  }
+  return fail("unknown op kind %d", op.d.kind);
+}
+
+int check_tap(dpb_engine* e, int tap, int nt) {
+  if (!e->ws) return fail("workspace not set (dpb_engine_set_workspace)");
+  if (tap < 0 || tap >= (int)e->bufs.size() || e->producer[tap] < 0) return fail("invalid tap buffer %d", tap);
+  if (e->bufs[tap].is_const) return fail("tap buffer %d does not depend on x", tap);
+  if (e->cur_batch <= 0) return fail("dpb_primal must run before jvp/vjp");
+  if (nt <= 0 || nt > e->maxT || nt % e->cur_batch) return fail("nt=%d must be a positive multiple of batch=%d and <= max_tangents=%d", nt, e->cur_batch, e->maxT);
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+const char* dpb_last_error(void) { return g_err; }
+int dpb_abi_version(void) { return DPB_ABI_VERSION; }
+
+int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
+  if (!net || !out) return fail("null argument");
+  if (net->dtype != DPB_F32 && net->dtype != DPB_BF16) return fail("bad dtype %d", net->dtype);
+  if (net->max_batch < 1 || net->max_tangents < 1) return fail("max_batch/max_tangents must be >= 1");
+  dpb_engine* e = new dpb_engine();
+  e->dtype = net->dtype;
+  e->es = net->dtype == DPB_F32 ? 4 : 2;
+  e->maxB = net->max_batch;
+  e->maxT = net->max_tangents;
+  e->x_buf = net->x_buf; e->x_channels = net->x_channels; e->temb_buf = net->temb_buf; e->temb_dim = net->temb_dim;
+  e->temb_flip = net->temb_flip_sin_to_cos; e->temb_hm1 = net->temb_half_minus_one; e->ctx_buf = net->ctx_buf;
+  const int nb = net->n_buffers;
+  e->bufs.resize(nb);
+  e->producer.assign(nb, -1);
+  auto bad = [&](const char* m, int i) { fail("op %d: %s", i, m); delete e; return -1; };
+  for (int i = 0; i < nb; ++i) {
+    e->bufs[i].rows = net->buffers[i].rows;
+    e->bufs[i].C = net->buffers[i].channels;
+    e->bufs[i].kind = net->buffers[i].kind;
+    if (e->bufs[i].rows < 1 || e->bufs[i].C < 8 || e->bufs[i].C % 8) { fail("buffer %d: rows=%d channels=%d (channels must be a multiple of 8)", i, e->bufs[i].rows, e->bufs[i].C); delete e; return -1; }
+  }
+  if (net->x_buf < 0 || net->x_buf >= nb) { fail("bad x_buf"); delete e; return -1; }
+  e->bufs[net->x_buf].is_const = false;
+  auto okb = [&](int b) { return b >= 0 && b < nb; };
+  for (int i = 0; i < net->n_ops; ++i) {
+    Op op;
+    op.d = net->ops[i];
+    const dpb_op_desc& d = op.d;
+    if (!okb(d.in0) || !okb(d.out)) return bad("bad buffer id", i);
+    bool c = e->bufs[d.in0].is_const;
+    if (d.kind == DPB_OP_ATTENTION || d.kind == DPB_OP_CONCAT) {
+      if (!okb(d.in1)) return bad("bad in1", i);
+      c = c && e->bufs[d.in1].is_const;
+    }
+    if (d.kind == DPB_OP_ATTENTION) {
+      if (!okb(d.in2)) return bad("bad in2", i);
+      c = c && e->bufs[d.in2].is_const;
+      AttnPlan p;
+      p.heads = d.ip[0];
+      if (p.heads < 1 || e->bufs[d.in0].C % p.heads) return bad("channels not divisible by heads", i);
+      p.d = e->bufs[d.in0].C / p.heads;
+      if (p.d % 8) return bad("head dim must be a multiple of 8", i);
+      p.Lq = e->bufs[d.in0].rows; p.Lk = e->bufs[d.in1].rows;
+      p.Lqp = round8(p.Lq); p.Lkp = round8(p.Lk);
+      if (e->bufs[d.in1].is_const != e->bufs[d.in2].is_const) return bad("k and v must both depend on x or both not", i);
+      if (e->bufs[d.in0].is_const) return bad("attention query independent of x is unsupported", i);
+      p.kv_const = e->bufs[d.in1].is_const;
+      op.attn = (int)e->plans.size();
+      e->plans.push_back(p);
+    }
+    if (d.kind == DPB_OP_CONV) {
+      if (d.res >= 0) { if (!okb(d.res)) return bad("bad res", i); c = c && e->bufs[d.res].is_const; }
+      if (d.rowbias >= 0 && (!okb(d.rowbias) || e->bufs[d.rowbias].kind != DPB_BUF_SHARED)) return bad("rowbias must be a SHARED buffer", i);
+      if (!d.w[0]) return bad("missing weight", i);
+      if (d.ip[2] != e->bufs[d.in0].C || e->bufs[d.out].C != round8(d.ip[5])) return bad("conv channel mismatch", i);
+    }
+    op.is_const = c;
+    e->bufs[d.out].is_const = c;
+    if (e->producer[d.out] >= 0) return bad("buffer written twice (tape must be SSA)", i);
+    e->producer[d.out] = i;
+    e->ops.push_back(op);
+  }
+  // ---------------- memory plan
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  const size_t es = e->es;
+  for (auto& b : e->bufs) {
+    size_t n = b.kind == DPB_BUF_SHARED ? 1 : e->maxB;
+    b.p_off = take(n * b.rows * (size_t)b.C * es);
+  }
+  for (auto& b : e->bufs)
+    if (!b.is_const) b.t_off = take((size_t)e->maxT * b.rows * b.C * es);
+  for (auto& b : e->bufs)
+    if (!b.is_const) b.g_off = take((size_t)e->maxT * b.rows * b.C * es);
+  size_t s1 = 0, s2 = 0, t1 = 0, dv = 0, ctmp = 0, maxrc = 0;
+  for (auto& op : e->ops) {
+    const dpb_op_desc& d = op.d;
+    if (d.kind == DPB_OP_ATTENTION) {
+      AttnPlan& p = e->plans[op.attn];
+      const size_t H = p.heads;
+      p.P = take((size_t)e->maxB * H * p.Lq * p.Lkp * es);
+      p.VT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
+      p.KT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
+      s1 = std::max(s1, (size_t)e->maxT * H * p.Lq * p.Lkp * es);
+      size_t lmax = std::max(p.Lqp, p.Lkp);
+      t1 = std::max(t1, (size_t)e->maxT * H * p.d * lmax * es);
+      if (!p.kv_const) {
+        p.PT = take((size_t)e->maxB * H * p.Lk * p.Lqp * es);
+        p.QT = take((size_t)e->maxB * H * p.d * p.Lqp * es);
+        s2 = std::max(s2, (size_t)e->maxT * H * p.Lk * p.Lqp * es);
+        dv = std::max(dv, (size_t)e->maxT * H * p.Lq * sizeof(float));
+      }
+    } else if (d.kind == DPB_OP_GROUPNORM) {
+      op.pstats = e->pstats_bytes;
+      e->pstats_bytes += (size_t)e->maxB * d.ip[0] * 2 * sizeof(double);
+      if (!op.is_const) {
+        op.tstats = e->tstats_bytes;
+        e->tstats_bytes += (size_t)e->maxT * d.ip[0] * 2 * sizeof(double);
+      }
+    } else if (d.kind == DPB_OP_CONV && d.ip[9] == DPB_GATHER_UPCONV && !op.is_const) {
+      ctmp = std::max(ctmp, (size_t)e->maxT * d.ip[3] * d.ip[4] * e->bufs[d.in0].C * es);
+    }
+  }
+  for (auto& b : e->bufs) maxrc = std::max(maxrc, (size_t)b.rows * b.C);
+  e->pstats_off = take(e->pstats_bytes);
+  e->tstats_off = take(e->tstats_bytes);
+  for (auto& op : e->ops)
+    if (op.d.kind == DPB_OP_GROUPNORM) { op.pstats += e->pstats_off; op.tstats += e->tstats_off; }
+  e->S1 = take(s1); e->S2 = take(s2); e->T1 = take(t1); e->Dv = take(dv); e->convtmp = take(ctmp);
+  const size_t nio = (size_t)std::max(e->maxB, e->maxT) * maxrc * sizeof(float);
+  e->io_in = take(nio);
+  e->io_out = take(nio);
+  e->orth = take(sizeof(double) * (3 * 16 * 16 + 2));
+  const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
+  e->pbV = 0; e->pbW = take((size_t)e->maxT * nx * sizeof(float)); e->pbVn = take((size_t)e->maxT * nx * sizeof(float));
+  e->ws_bytes = off;
+  e->ginit.assign(nb, 0);
+  *out = e;
+  return 0;
+}
+
+void dpb_engine_destroy(dpb_engine* e) { delete e; }
+
+int dpb_engine_set_stream(dpb_engine* e, void* s) {
+  if (!e) return fail("null engine");
+  e->stream = (hipStream_t)s;
+  return 0;
+}
+
+size_t dpb_engine_workspace_bytes(const dpb_engine* e) { return e ? e->ws_bytes : 0; }
+
+int dpb_engine_set_workspace(dpb_engine* e, void* ws, size_t bytes) {
+  if (!e || !ws) return fail("null argument");
+  if (bytes < e->ws_bytes) return fail("workspace too small: %zu < %zu", bytes, e->ws_bytes);
+  if ((uintptr_t)ws % 256) return fail("workspace must be 256-byte aligned");
+  e->ws = (char*)ws;
+  e->cur_batch = 0;
+  DPB_CHECK(hipMemsetAsync(ws, 0, e->ws_bytes, e->stream));
+  return 0;
+}
+
+int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf) {
+  if (!e || !x) return fail("null argument");
+  if (!e->ws) return fail("workspace not set (dpb_engine_set_workspace)");
+  if (batch < 1 || batch > e->maxB) return fail("batch=%d outside [1,%d]", batch, e->maxB);
+  if (upto_buf < 0 || upto_buf >= (int)e->bufs.size() || e->producer[upto_buf] < 0) return fail("invalid upto buffer %d", upto_buf);
+  e->n_launch = 0; e->flops = 0; e->gbytes = 0;
+  const Buf& bx = e->bufs[e->x_buf];
+  e->n_launch++;
+  if (int r = launch_nchw_to_nhwc(e->dtype, x, e->P(e->x_buf), batch, e->x_channels, bx.rows, bx.C, e->stream)) return r;
+  if (e->ctx_buf >= 0) {
+    if (!ctx) return fail("this network needs ctx (encoder_hidden_states)");
+    const Buf& bc = e->bufs[e->ctx_buf];
+    // ctx is already [batch][rows][C] channel-last: a "transpose" with C=HW roles swapped is not needed; cast via nchw kernel with HW=1
+    e->n_launch++;
+    if (int r = launch_nchw_to_nhwc(e->dtype, ctx, e->P(e->ctx_buf), batch * bc.rows, bc.C, 1, bc.C, e->stream)) return r;
+  }
+  if (e->temb_buf >= 0) {
+    // sinusoidal timestep embedding, computed on the host in fp32 exactly as the reference frameworks do
+    // (diffusion.py:783-804 / diffusers Timesteps), uploaded through the io staging area.
+    const int dim = e->temb_dim, half = dim / 2;
+    std::vector<float> emb(e->bufs[e->temb_buf].C, 0.f);
+    for (int i = 0; i < half; ++i) {
+      float f;
+      if (e->temb_hm1) f = expf((float)i * (float)(-(log(10000.0) / (double)(half - 1))));   // diffusion.py:797-798
+      else f = expf(((float)(-log(10000.0)) * (float)i) / (float)half);                      // diffusers get_timestep_embedding
+      float ang = t * f;
+      float s = sinf(ang), c = cosf(ang);
+      if (e->temb_flip) { emb[i] = c; emb[half + i] = s; } else { emb[i] = s; emb[half + i] = c; }
+    }
+    float* stage = (float*)(e->ws + e->io_in);
+    DPB_CHECK(hipMemcpyAsync(stage, emb.data(), emb.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    DPB_CHECK(hipStreamSynchronize(e->stream));   // emb is a host temporary
+    e->n_launch++;
+    if (int r = launch_nchw_to_nhwc(e->dtype, stage, e->P(e->temb_buf), 1, (int)emb.size(), 1, (int)emb.size(), e->stream)) return r;
+  }
+  if (e->pstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));
+  e->cur_batch = batch;
+  const int last = e->producer[upto_buf];
+  for (int i = 0; i <= last; ++i)
+    if (int r = run_op(e, e->ops[i], MODE_PRIMAL, batch)) return r;
+  return 0;
+}
+
+int dpb_read_buffer(dpb_engine* e, int buf, int channels, float* out) {
+  if (!e || !out) return fail("null argument");
+  if (buf < 0 || buf >= (int)e->bufs.size()) return fail("bad buffer %d", buf);
+  const Buf& b = e->bufs[buf];
+  if (channels < 1 || channels > b.C) return fail("bad channel count");
+  int n = b.kind == DPB_BUF_SHARED ? 1 : e->cur_batch;
+  return launch_nhwc_to_nchw(e->dtype, e->P(buf), out, n, channels, b.rows, b.C, e->stream);
+}
+
+int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
+  if (!e || !V || !U) return fail("null argument");
+  if (int r = check_tap(e, tap, nt)) return r;
+  e->n_launch = 0; e->flops = 0; e->gbytes = 0;
+  const Buf& bx = e->bufs[e->x_buf];
+  e->n_launch++;
+  if (int r = launch_nchw_to_nhwc(e->dtype, V, e->T(e->x_buf), nt, e->x_channels, bx.rows, bx.C, e->stream)) return r;
+  if (e->tstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
+  const int last = e->producer[tap];
+  for (int i = 0; i <= last; ++i) {
+    if (e->ops[i].is_const) continue;
+    if (int r = run_op(e, e->ops[i], MODE_TANGENT, nt)) return r;
+  }
+  const Buf& bt = e->bufs[tap];
+  e->n_launch++;
+  return launch_nhwc_to_nchw(e->dtype, e->T(tap), U, nt, bt.C, bt.rows, bt.C, e->stream);
+}
+
+int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
+  if (!e || !U || !W) return fail("null argument");
+  if (int r = check_tap(e, tap, nt)) return r;
+  e->n_launch = 0; e->flops = 0; e->gbytes = 0;
+  const Buf& bt = e->bufs[tap];
+  std::fill(e->ginit.begin(), e->ginit.end(), 0);
+  e->n_launch++;
+  if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.C, bt.rows, bt.C, e->stream)) return r;
+  e->ginit[tap] = 1;
+  if (e->tstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
+  for (int i = e->producer[tap]; i >= 0; --i) {
+    const Op& op = e->ops[i];
+    if (op.is_const || !e->ginit[op.d.out]) continue;
+    if (int r = run_op(e, op, MODE_ADJOINT, nt)) return r;
+  }
+  if (!e->ginit[e->x_buf]) return fail("tap buffer %d is not connected to x", tap);
+  const Buf& bx = e->bufs[e->x_buf];
+  e->n_launch++;
+  return launch_nhwc_to_nchw(e->dtype, e->G(e->x_buf), W, nt, e->x_channels, bx.rows, bx.C, e->stream);
+}
+
+int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N, void* stream) {
+  if (!W || !Vprev || !V || !s || !conv || !scratch) return fail("null argument");
+  OrthArgs a;
+  a.W = W; a.Vprev = Vprev; a.V = V; a.s = s; a.conv = conv; a.scratch = (double*)scratch; a.k = k; a.N = N;
+  return launch_orth(a, (hipStream_t)stream);
+}
+
+int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, float* conv, int k, int n_iters) {
+  if (!e || !V || !U || !s || !conv) return fail("null argument");
+  if (e->cur_batch != 1) return fail("dpb_pullback_iterate handles a single sample (batch 1); got batch %d", e->cur_batch);
+  if (k < 1 || k > 16) return fail("pca_rank k=%d outside [1,16]", k);
+  if (int r = check_tap(e, tap, k)) return r;
+  const long N = (long)e->bufs[e->x_buf].rows * e->x_channels;
+  float* Wm = (float*)(e->ws + e->pbW);
+  float* Vn = (float*)(e->ws + e->pbVn);
+  long launches = 0; double fl = 0, gb = 0;
+  for (int it = 0; it < n_iters; ++it) {
+    if (int r = dpb_jvp(e, tap, V, k, U)) return r;
+    launches += e->n_launch; fl += e->flops; gb += e->gbytes;
+    if (int r = dpb_vjp(e, tap, U, k, Wm)) return r;
+    launches += e->n_launch; fl += e->flops; gb += e->gbytes;
+    if (int r = dpb_orth(Wm, V, Vn, s, conv, e->ws + e->orth, k, N, e->stream)) return r;
+    DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * k * N, hipMemcpyDeviceToDevice, e->stream));
+    launches += 6;
+  }
+  e->n_launch = launches; e->flops = fl; e->gbytes = gb;
+  return 0;
+}
+
+int dpb_ddim_step(const float* x, const float* eps, float* out, float* x0, int64_t n, float a_t, float a_next, void* stream) {
+  if (!x || !eps || !out) return fail("null argument");
+  return launch_ddim_step(x, eps, out, x0, n, a_t, a_next, (hipStream_t)stream);
+}
+
+int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int64_t n, float a, float b, float c, void* stream) {
+  if (!x || !y || !out) return fail("null argument");
+  return launch_lincomb(x, y, z, out, n, a, b, c, (hipStream_t)stream);
+}
+
+int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes) {
+  if (!e) return fail("null engine");
+  if (launches) *launches = e->n_launch;
+  if (gemm_flops) *gemm_flops = e->flops;
+  if (gemm_bytes) *gemm_bytes = e->gbytes;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Host-side launch interface of the gfx950 kernels (internal; the public C-ABI is include/dpb.h).
+#pragma once
+#include "common.h"
+
+namespace dpb {
+
+// ---------------------------------------------------------------- GEMM / implicit-GEMM convolution
+// C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k]  (+bias[n]) (+rowbias[sample(m)][n]) (+R[z][m][n]) (+C if accumulate)
+// A: plain rows (lda) or gathered NHWC pixels (conv).  B is always [N][K], K contiguous.
+enum { GATHER_NONE = 0, GATHER_CONV = 1, GATHER_CONVT = 2, GATHER_UPCONV = 3 };
+struct GemmArgs {
+  const void* A = nullptr; const void* B = nullptr; void* C = nullptr; const void* R = nullptr;
+  const float* bias = nullptr;
+  const void* rowbias = nullptr;      // [samples][N] in T; sample(m) = (m / rows_per_sample) / rowbias_div
+  int rows_per_sample = 1, rowbias_div = 1;
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldc = 0, ldr = 0;
+  // two-level batch z = z1 * Z2 + z2 ; per-operand offset = (z1 / div) * s1 + z2 * s2  (elements)
+  int Z1 = 1, Z2 = 1;
+  long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sC1 = 0, sC2 = 0, sR1 = 0, sR2 = 0;
+  int divA = 1, divB = 1;
+  float alpha = 1.f;
+  int accumulate = 0;
+  // gather description (A is [samples][H*W][Cin] NHWC, output pixels Ho x Wo, KS x KS taps)
+  int gather = GATHER_NONE;
+  int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, KS = 1, stride = 1, pad = 0;
+};
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- normalisation
+enum { MODE_PRIMAL = 0, MODE_TANGENT = 1, MODE_ADJOINT = 2 };
+struct GNArgs {
+  const void* x = nullptr;        // primal input  [Bp][HW][C]
+  const void* d = nullptr;        // tangent dx or cotangent gz [NT][HW][C] (modes 1,2)
+  void* y = nullptr;              // output (primal y / tangent dz / cotangent gx)
+  const float* gamma = nullptr; const float* beta = nullptr;
+  double* pstats = nullptr;       // [Bp][G][2]  primal (sum, sumsq) -> finalised to (mean, rstd) in place
+  double* tstats = nullptr;       // [NT][G][2]  tangent / adjoint sums
+  int Bp = 1, NT = 0, kps = 1;    // tangent j belongs to primal sample j / kps
+  int HW = 0, C = 0, G = 32;
+  float eps = 1e-5f;
+  int silu = 0, accumulate = 0;
+};
+int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st);
+
+struct LNArgs {
+  const void* x = nullptr; const void* d = nullptr; void* y = nullptr;
+  const float* gamma = nullptr; const float* beta = nullptr;
+  int rows_per_sample = 0, Bp = 1, NT = 0, kps = 1, C = 0;
+  float eps = 1e-5f;
+  int accumulate = 0;
+};
+int launch_layernorm(int dtype, int mode, const LNArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- attention pieces
+// rows: Z * Lq rows of length ld (valid columns < Lk, the rest are written as 0)
+int launch_softmax_fwd(int dtype, void* S, long Z, int Lq, int Lk, int ld, hipStream_t st);
+// dP = P o (dS - rowsum(P o dS)), in place on dS; P row index uses z_p = (z / Z2 / kps) * Z2 + z % Z2; optional D out
+int launch_softmax_jvp(int dtype, const void* P, void* dS, float* D, long Z, int Z2, int kps, int Lq, int Lk, int ld,
+                       hipStream_t st);
+// gST[z][j][i] = PT[zp][j][i] * (gPT[z][j][i] - D[z][i])   (in place on gPT)
+int launch_softmax_adjT(int dtype, const void* PT, void* gPT, const float* D, long Z, int Z2, int kps, int Lk, int Lq,
+                        int ld, hipStream_t st);
+// out[z][c][r] = in[z][r][c] for r < R, c < Ccols ; in row stride ldin, in batch strides (s1 over z1, s2 over z2)
+int launch_transpose(int dtype, const void* in, void* out, int Z1, int Z2, long s1, long s2, int R, int Ccols, int ldin,
+                     int ldout, long outZstride, hipStream_t st);
+
+// ---------------------------------------------------------------- elementwise
+struct GegluArgs {
+  const void* h = nullptr;     // primal [Bp*rows][2F]
+  const void* d = nullptr;     // tangent dh [NT*rows][2F] or cotangent gy [NT*rows][F]
+  void* y = nullptr;           // primal y [.. F] / tangent dy [.. F] / cotangent gh [.. 2F]
+  int rows_per_sample = 0, Bp = 1, NT = 0, kps = 1, F = 0;
+  int accumulate = 0;
+};
+int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st);
+int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st);
+int launch_axpy(int dtype, const void* x, void* y, long n, int accumulate, hipStream_t st);   // y (+)= x
+// channel concat / split on [rows][C] tensors: copy src[rows][Cs] <-> dst[rows][Cd] column window at c0
+int launch_copy_cols(int dtype, const void* src, int lds, int cs0, void* dst, int ldd, int cd0, long rows, int ncols,
+                     int accumulate, hipStream_t st);
+// fp32 NCHW [n][C][HW]  <->  T NHWC [n][HW][Cpad]
+int launch_nchw_to_nhwc(int dtype, const float* src, void* dst, int n, int C, int HW, int Cpad, hipStream_t st);
+int launch_nhwc_to_nchw(int dtype, const void* src, float* dst, int n, int C, int HW, int Cpad, hipStream_t st);
+// 2x2 sum pooling of a cotangent (adjoint of nearest x2 upsampling): in [n][2H*2W][C] -> out [n][H*W][C]
+int launch_pool2x2_sum(int dtype, const void* in, void* out, int n, int H, int W, int C, int accumulate, hipStream_t st);
+
+// ---------------------------------------------------------------- re-orthonormalisation (fp32 in/out, fp64 Gram)
+struct OrthArgs {
+  const float* W = nullptr;      // [k][N]  = J^T J V_prev
+  const float* Vprev = nullptr;  // [k][N]
+  float* V = nullptr;            // [k][N]  right singular vectors of W, rows, descending
+  float* s = nullptr;            // [k]     sqrt(singular values of W)   (reference: s.sqrt())
+  float* conv = nullptr;         // [2]     {||V - Vprev||_2, max(|V-Vprev| - 1e-5|V|)}
+  double* scratch = nullptr;     // >= 3*k*k + 2*k + 4 doubles
+  int k = 0; long N = 0;
+};
+int launch_orth(const OrthArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- DDIM
+// x_next = sqrt(a_next) * (x - e*sqrt(1-a_t))/sqrt(a_t) + sqrt(1-a_next) * e      (fp32, elementwise)
+int launch_ddim_step(const float* x, const float* e, float* out, float* x0, long n, float a_t, float a_next, hipStream_t st);
+// out = a*x + b*y + c*z (z may be null)
+int launch_lincomb(const float* x, const float* y, const float* z, float* out, long n, float a, float b, float c, hipStream_t st);
+
+}  // namespace dpb

@@ -1,0 +1,178 @@
+// Re-orthonormalisation step of the subspace iteration: thin SVD of the k x N matrix W = J^T J V_prev
+// (k <= 16, N up to 196 608), fp32 in/out with fp64 Gram and eigen-solve.
+//
+// Replaces torch.linalg.svd(v_, full_matrices=False) at reference src/utils/utils.py:799 (and :233):
+//   W = U S V^T  ->  rows of V^T (descending S) and s = sqrt(S).
+// Method: G = W W^T (k x k, fp64) -> cyclic Jacobi eigen-decomposition G = Q L Q^T on one thread
+// -> V^T = L^-1/2 Q^T W.  One streaming pass over W for G, one for V^T: HBM/L2-bound, ~2 reads + 1
+// write of k*N floats.  LAPACK leaves the sign of each singular vector arbitrary; here each row is
+// signed to have non-negative overlap with the previous iterate (needs W V_prev^T, accumulated in the
+// same pass), which makes the reference's stop rule allclose(V_prev, V) well defined.
+// Also emits ||V - V_prev||_2 and max(|V - V_prev| - 1e-5 |V|) so the stop test (utils.py:803-806)
+// needs a single 8-byte read-back.
+#include "kernels.h"
+
+namespace dpb {
+
+constexpr int KMAX = 16;
+
+// grid (nblk, k): block row i accumulates G[i][:] and X[i][:] = W_i . Vprev_j over a slice of N
+__global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* Vp, double* G, double* X, int k, long N) {
+  const int i = blockIdx.y;
+  float g[KMAX], x[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) g[j] = x[j] = 0.f;
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)gridDim.x * 256) {
+    const float wi = W[(long)i * N + n];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < k) {
+        g[j] += wi * W[(long)j * N + n];
+        x[j] += wi * Vp[(long)j * N + n];
+      }
+    }
+  }
+  __shared__ float red[2][KMAX][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < k) {
+      float a = wave_sum(g[j]), b = wave_sum(x[j]);
+      if (lane == 0) { red[0][j][wave] = a; red[1][j][wave] = b; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * KMAX) {
+    int w = threadIdx.x / KMAX, j = threadIdx.x % KMAX;
+    if (j < k) {
+      double s = (double)red[w][j][0] + red[w][j][1] + red[w][j][2] + red[w][j][3];
+      atomicAdd((w == 0 ? G : X) + i * k + j, s);
+    }
+  }
+}
+
+// one wave: parallel cyclic Jacobi eigen-solve of the symmetric k x k Gram matrix (thread r owns row/col r),
+// then the mixing matrix Cm with V_i = sum_j Cm[i][j] W_j.
+__global__ __launch_bounds__(64) void eig_kernel(const double* G, const double* X, double* Cm, float* s_out, int k) {
+  __shared__ double A[KMAX][KMAX + 1], Q[KMAX][KMAX + 1];
+  __shared__ int order[KMAX];
+  const int r = threadIdx.x;
+  if (r < k)
+    for (int j = 0; j < k; ++j) {
+      A[r][j] = 0.5 * (G[r * k + j] + G[j * k + r]);
+      Q[r][j] = r == j ? 1.0 : 0.0;
+    }
+  __syncthreads();
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int p = 0; p < k - 1; ++p)
+      for (int q = p + 1; q < k; ++q) {
+        const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+        __syncthreads();
+        if (fabs(apq) <= 1e-300 || fabs(apq) <= 1e-18 * sqrt(fabs(app * aqq))) continue;   // uniform
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        if (r < k) {                       // A <- A J   (row r)
+          double arp = A[r][p], arq = A[r][q];
+          A[r][p] = c * arp - s * arq;
+          A[r][q] = s * arp + c * arq;
+          double qrp = Q[r][p], qrq = Q[r][q];
+          Q[r][p] = c * qrp - s * qrq;
+          Q[r][q] = s * qrp + c * qrq;
+        }
+        __syncthreads();
+        if (r < k) {                       // A <- J^T A (column r)
+          double apr = A[p][r], aqr = A[q][r];
+          A[p][r] = c * apr - s * aqr;
+          A[q][r] = s * apr + c * aqr;
+        }
+        __syncthreads();
+      }
+  }
+  if (r == 0) {
+    for (int i = 0; i < k; ++i) order[i] = i;
+    for (int i = 0; i < k; ++i)          // selection sort, descending eigenvalue
+      for (int j = i + 1; j < k; ++j)
+        if (A[order[j]][order[j]] > A[order[i]][order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+  }
+  __syncthreads();
+  if (r < k) {
+    const int i = r, e = order[i];
+    double lam = A[e][e] > 0 ? A[e][e] : 0.0;
+    double sig = sqrt(lam);                       // singular value of W
+    s_out[i] = (float)sqrt(sig);                  // reference returns s.sqrt() (utils.py:810)
+    double inv = sig > 1e-150 ? 1.0 / sig : 0.0;
+    double dot = 0;
+    for (int j = 0; j < k; ++j) dot += Q[j][e] * inv * X[j * k + i];
+    double sgn = dot < 0 ? -1.0 : 1.0;
+    for (int j = 0; j < k; ++j) Cm[i * k + j] = sgn * Q[j][e] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void orth_apply_kernel(const float* W, const float* Vp, float* V, const double* Cm, double* acc, int k,
+                                                         long N) {
+  __shared__ double cm[KMAX * KMAX];
+  for (int i = threadIdx.x; i < k * k; i += 256) cm[i] = Cm[i];
+  __syncthreads();
+  double d2 = 0;
+  float viol = 0.f;
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)gridDim.x * 256) {
+    float w[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) w[j] = j < k ? W[(long)j * N + n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      if (i < k) {
+        double v = 0;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j < k) v += cm[i * k + j] * (double)w[j];
+        float vf = (float)v;
+        float dlt = Vp[(long)i * N + n] - vf;
+        V[(long)i * N + n] = vf;
+        d2 += (double)dlt * dlt;
+        viol = fmaxf(viol, fabsf(dlt) - 1e-5f * fabsf(vf));
+      }
+    }
+  }
+  // block reduce
+  __shared__ double rd[4];
+  __shared__ float rv[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    d2 += __shfl_xor(d2, o, 64);
+    viol = fmaxf(viol, __shfl_xor(viol, o, 64));
+  }
+  if (lane == 0) { rd[wave] = d2; rv[wave] = viol; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], rd[0] + rd[1] + rd[2] + rd[3]);
+    float m = fmaxf(fmaxf(rv[0], rv[1]), fmaxf(rv[2], rv[3]));
+    atomicMax(reinterpret_cast<unsigned long long*>(&acc[1]), (unsigned long long)__float_as_uint(fmaxf(m, 0.f)));
+  }
+}
+
+__global__ void orth_finish_kernel(const double* acc, float* conv) {
+  conv[0] = (float)sqrt(acc[0]);
+  conv[1] = __uint_as_float((unsigned)(*reinterpret_cast<const unsigned long long*>(&acc[1])));
+}
+
+int launch_orth(const OrthArgs& a, hipStream_t st) {
+  if (a.k < 1 || a.k > KMAX) { set_error("orth: pca_rank k=%d outside [1,%d]", a.k, KMAX); return -1; }
+  const int k = a.k;
+  double* G = a.scratch;
+  double* X = G + k * k;
+  double* Cm = X + k * k;
+  double* acc = Cm + k * k;
+  DPB_CHECK(hipMemsetAsync(a.scratch, 0, sizeof(double) * (3 * k * k + 2), st));
+  unsigned nb = (unsigned)((a.N + 2047) / 2048);
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(gram_kernel, dim3(nb, k), dim3(256), 0, st, a.W, a.Vprev, G, X, k, a.N);
+  hipLaunchKernelGGL(eig_kernel, dim3(1), dim3(64), 0, st, G, X, Cm, a.s, k);
+  hipLaunchKernelGGL(orth_apply_kernel, dim3(nb), dim3(256), 0, st, a.W, a.Vprev, a.V, Cm, acc, k, a.N);
+  hipLaunchKernelGGL(orth_finish_kernel, dim3(1), dim3(1), 0, st, acc, a.conv);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dpb

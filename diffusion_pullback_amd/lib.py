@@ -1,0 +1,98 @@
+"""ctypes binding of libdpb.so (the C ABI declared in include/dpb.h).
+
+There is NO fallback: if the HIP library is missing or a symbol cannot be bound this
+module raises, so nothing in the product path can silently run on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpb.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DPB_F32, DPB_BF16 = 0, 1
+OP_CONV, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_GEGLU, OP_SILU, OP_CONCAT = 1, 2, 3, 4, 5, 6, 7
+GATHER_NONE, GATHER_CONV, GATHER_UPCONV = 0, 1, 3
+BUF_ACT, BUF_SHARED = 0, 1
+
+
+class BufferDesc(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("channels", C.c_int32), ("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in0", C.c_int32), ("in1", C.c_int32), ("in2", C.c_int32), ("out", C.c_int32),
+                ("res", C.c_int32), ("rowbias", C.c_int32), ("ip", C.c_int32 * 12), ("fp", C.c_float * 4),
+                ("w", C.c_void_p * 4)]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_tangents", C.c_int32), ("n_buffers", C.c_int32),
+                ("n_ops", C.c_int32), ("buffers", C.POINTER(BufferDesc)), ("ops", C.POINTER(OpDesc)),
+                ("x_buf", C.c_int32), ("x_channels", C.c_int32), ("temb_buf", C.c_int32), ("temb_dim", C.c_int32),
+                ("temb_flip_sin_to_cos", C.c_int32), ("temb_half_minus_one", C.c_int32), ("ctx_buf", C.c_int32)]
+
+
+# every symbol include/dpb.h declares: name -> (restype, argtypes)
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SYMBOLS = {
+    "dpb_last_error": (C.c_char_p, []),
+    "dpb_abi_version": (_I, []),
+    "dpb_engine_create": (_I, [C.POINTER(NetDesc), C.POINTER(_P)]),
+    "dpb_engine_destroy": (None, [_P]),
+    "dpb_engine_set_stream": (_I, [_P, _P]),
+    "dpb_engine_workspace_bytes": (C.c_size_t, [_P]),
+    "dpb_engine_set_workspace": (_I, [_P, _P, C.c_size_t]),
+    "dpb_primal": (_I, [_P, _P, _I, _F, _P, _I]),
+    "dpb_read_buffer": (_I, [_P, _I, _I, _P]),
+    "dpb_jvp": (_I, [_P, _I, _P, _I, _P]),
+    "dpb_vjp": (_I, [_P, _I, _P, _I, _P]),
+    "dpb_orth": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P]),
+    "dpb_pullback_iterate": (_I, [_P, _I, _P, _P, _P, _P, _I, _I]),
+    "dpb_ddim_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
+    "dpb_lincomb": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _P]),
+    "dpb_engine_stats": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class DpbError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libdpb.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise DpbError("hipcc build of libdpb.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """Load libdpb.so and bind every declared symbol; raises loudly if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpbError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the product path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dpb_abi_version() != 1:
+        raise DpbError("libdpb.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise DpbError(load().dpb_last_error().decode())

@@ -1,0 +1,136 @@
+/* dpb.h -- C ABI of the MI355X-native pullback engine (libdpb.so, gfx950).
+ *
+ * Drop-in boundary for ONE path of enkeejunior1/Diffusion-Pullback: the power-iteration
+ * low-rank SVD of the U-Net latent->feature Jacobian and the U-Net forwards of the DDIM loop.
+ * The reference has no FFI (it is pure Python over diffusers); its boundary is Python method
+ * injection onto the U-Net object (reference src/utils/utils.py:103-104, :326-337).  The host
+ * shim diffusion_pullback_amd/ re-creates those methods on top of the entry points below;
+ * INTEGRATION.md shows the binding a maintainer would add.  Each entry point cites the
+ * reference code it replaces.
+ *
+ * Conventions: plain pointers and sizes, no torch types.  All tensor pointers are DEVICE
+ * pointers unless marked host.  Every call enqueues work on the engine's stream
+ * (dpb_engine_set_stream; default stream 0) and returns without synchronising unless stated.
+ * Return value: 0 = success, nonzero = failure (message via dpb_last_error()).  One engine per
+ * GPU per process; calls on one engine must not overlap (thread-compatible, not thread-safe).
+ * The engine never allocates device memory: the caller sizes (dpb_engine_workspace_bytes) and
+ * provides (dpb_engine_set_workspace) one zero-initialisable workspace, and owns the weights.
+ */
+#ifndef DPB_H
+#define DPB_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPB_ABI_VERSION 1
+
+enum { DPB_F32 = 0, DPB_BF16 = 1 };   /* storage + MFMA input type; accumulation is always fp32 */
+
+/* ---- network description: a tape of NHWC ops over numbered activation buffers ------------- */
+enum {
+  DPB_OP_CONV = 1,      /* conv KSxKS / 1x1 / Linear: out = W*in (+bias) (+rowbias[temb]) (+res)      */
+  DPB_OP_GROUPNORM = 2, /* GroupNorm(G, eps) (+SiLU)                                                   */
+  DPB_OP_LAYERNORM = 3, /* LayerNorm over channels                                                     */
+  DPB_OP_ATTENTION = 4, /* multi-head softmax(q k^T d^-1/2) v ; in0=q in1=k in2=v                      */
+  DPB_OP_GEGLU = 5,     /* [rows][2F] -> [rows][F] : a * gelu_erf(g)                                   */
+  DPB_OP_SILU = 6,      /* elementwise x*sigmoid(x)                                                    */
+  DPB_OP_CONCAT = 7     /* channel concat of in0, in1                                                  */
+};
+enum { DPB_GATHER_NONE = 0, DPB_GATHER_CONV = 1, DPB_GATHER_UPCONV = 3 };
+enum { DPB_BUF_ACT = 0,     /* per-sample activation [rows][channels]                                   */
+       DPB_BUF_SHARED = 1   /* one copy shared by the batch, independent of x (time-embedding path)     */ };
+
+typedef struct dpb_buffer_desc {
+  int32_t rows;       /* H*W or token count, per sample */
+  int32_t channels;   /* stored channel count (multiple of 8) */
+  int32_t kind;       /* DPB_BUF_* */
+  int32_t reserved;
+} dpb_buffer_desc;
+
+typedef struct dpb_op_desc {
+  int32_t kind;              /* DPB_OP_* */
+  int32_t in0, in1, in2;     /* input buffer ids, -1 = none */
+  int32_t out;               /* output buffer id */
+  int32_t res;               /* CONV: buffer added to the output (residual / shortcut), -1 = none */
+  int32_t rowbias;           /* CONV: DPB_BUF_SHARED buffer [1][Cout] added to every row (temb projection), -1 */
+  int32_t ip[12];            /* CONV: H W Cin Ho Wo Cout KS stride pad gather ; GROUPNORM: G silu ;
+                                ATTENTION: heads ; GEGLU: F                                                  */
+  float fp[4];               /* GROUPNORM/LAYERNORM: eps */
+  const void* w[4];          /* CONV: w[0]=W [Cout][KS*KS*Cin] (engine dtype), w[1]=W^T [Cin][KS*KS*Cout]
+                                (engine dtype, for the adjoint; may be NULL for ops never differentiated),
+                                w[2]=bias fp32 [Cout] or NULL ; norms: w[0]=gamma fp32, w[1]=beta fp32   */
+} dpb_op_desc;
+
+typedef struct dpb_net_desc {
+  int32_t dtype;             /* DPB_F32 | DPB_BF16 */
+  int32_t max_batch;         /* max primal samples per call */
+  int32_t max_tangents;      /* max total tangents/cotangents per call (k * samples) */
+  int32_t n_buffers, n_ops;
+  const dpb_buffer_desc* buffers;
+  const dpb_op_desc* ops;
+  int32_t x_buf;             /* input buffer (NHWC, channels padded); x_channels true channels */
+  int32_t x_channels;
+  int32_t temb_buf;          /* DPB_BUF_SHARED [1][temb_dim] sinusoid input, -1 = none */
+  int32_t temb_dim;
+  int32_t temb_flip_sin_to_cos;   /* 1: [cos|sin] (diffusers SD), 0: [sin|cos] (DDPM) */
+  int32_t temb_half_minus_one;    /* 1: exponent denominator half_dim-1 (DDPM), 0: half_dim (SD) */
+  int32_t ctx_buf;           /* per-sample conditioning buffer [ctx_len][ctx_dim], -1 = none */
+} dpb_net_desc;
+
+typedef struct dpb_engine dpb_engine;
+
+const char* dpb_last_error(void);
+int dpb_abi_version(void);
+
+/* Build the executor for a network.  Weight pointers in `net` must stay valid for the engine's life.
+ * Replaces: the diffusers U-Net module tree the reference walks in get_h (utils.py:438-527, :114-163). */
+int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out);
+void dpb_engine_destroy(dpb_engine* e);
+int dpb_engine_set_stream(dpb_engine* e, void* hip_stream);
+size_t dpb_engine_workspace_bytes(const dpb_engine* e);
+/* `ws` must be 256-byte aligned device memory of at least workspace_bytes; it is zero-filled here. */
+int dpb_engine_set_workspace(dpb_engine* e, void* ws, size_t bytes);
+
+/* Primal pass: run ops up to (and including) the producer of `upto_buf`, keeping every activation
+ * and normalisation statistic resident for the tangent/adjoint passes.
+ * x: fp32 NCHW [batch][x_channels][rows(x_buf)], t: timestep (host float, shared by the batch),
+ * ctx: fp32 [batch][ctx_len][ctx_dim] or NULL.
+ * Replaces: unet.get_h(...) / unet(x, t, encoder_hidden_states) (utils.py:438-527; edit.py:454-458). */
+int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf);
+/* Copy a primal activation out as fp32 NCHW [batch][channels][rows] (first `channels` channels). */
+int dpb_read_buffer(dpb_engine* e, int buf, int channels, float* out);
+
+/* U = J V : forward-mode pass of `nt` tangents through the same kernels (nt = batch * tangents per
+ * sample, tangent j belongs to sample j / (nt/batch)).  V fp32 NCHW [nt][x_channels][rows(x)],
+ * U fp32 NCHW [nt][channels(tap)][rows(tap)].   Replaces: torch.func.jacfwd block, utils.py:766-775. */
+int dpb_jvp(dpb_engine* e, int tap_buf, const float* V, int nt, float* U);
+/* W = J^T U : adjoint pass wrt the input only.  Replaces: autograd.functional.jacobian, utils.py:790-797. */
+int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
+
+/* Thin SVD of W [k][N] (fp32): V rows = right singular vectors (descending), s = sqrt(singular values),
+ * conv[0] = ||V - Vprev||_2, conv[1] = max(|V - Vprev| - 1e-5|V|).  scratch: >= 8*(3*k*k+2) bytes.
+ * Replaces: torch.linalg.svd + dist/allclose inputs, utils.py:799-806.  Engine-independent. */
+int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
+             void* hip_stream);
+
+/* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev.
+ * V [k][N_in] in/out, U [k][N_h] out, s [k] out, conv [2] out (of the last iteration).
+ * Replaces: the loop body utils.py:756-808 (k <= 16, single sample). */
+int dpb_pullback_iterate(dpb_engine* e, int tap_buf, float* V, float* U, float* s, float* conv, int k, int n_iters);
+
+/* DDIM update (utils.py:301-306 / :1220-1225, eta = 0) and the x-space-guidance axpy (edit.py:490, :501). */
+int dpb_ddim_step(const float* x, const float* eps, float* out, float* x0, int64_t n, float alpha_t, float alpha_next,
+                  void* hip_stream);
+int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int64_t n, float a, float b, float c,
+                void* hip_stream);
+
+/* Introspection used by tests / bench: number of kernel launches and algorithmic GEMM flops of the last pass. */
+int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPB_H */

@@ -1,0 +1,163 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path behind the C ABI vs the CPU oracle.
+
+Tolerances: fp32 engine vs fp32 oracle -- relative Frobenius error <= 2e-4 per pass (different
+accumulation order only); bf16 engine vs fp32 oracle -- <= 4e-2 per pass, top singular vectors
+|cos| >= 0.99 (BASELINE.json north_star)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from _util import abs_cos, load_golden, oracle_jvp, oracle_vjp, rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return "cuda:0"
+
+
+def _toy_sd():
+    from oracle import unet_sd
+    f = load_golden("pullback_zt_tiny.pt")
+    cfg = unet_sd.SDConfig(**f["cfg"])
+    p = unet_sd.init_params(cfg, seed=f["seed"], gain=f["gain"])
+    return f, cfg, p
+
+
+def _small_ddpm():
+    from oracle import unet_ddpm
+    f = load_golden("ddpm_small.pt")
+    cfg = unet_ddpm.DDPMConfig(**f["cfg"])
+    return f, cfg, unet_ddpm.init_params(cfg, seed=f["seed"])
+
+
+def check_passes(net, fwd, x, t, ctx, taps, dtype, k=3, seed=0, report=None):
+    g = torch.Generator().manual_seed(seed)
+    tol = TOL[dtype]
+    errs = {}
+    for tap in taps:
+        f = lambda a: fwd(a, tap)
+        with torch.no_grad():
+            h_ref = f(x)
+        net.engine.primal(x, t, ctx, tap)
+        h = net.engine.read(tap).cpu()
+        V = torch.randn(k, x.numel(), generator=g)
+        U = net.engine.jvp(tap, V.to("cuda:0")).cpu()
+        U_ref = oracle_jvp(f, x, V)
+        Uc = torch.randn(k, h_ref.numel(), generator=g)
+        W = net.engine.vjp(tap, Uc.to("cuda:0")).cpu()
+        W_ref = oracle_vjp(f, x, Uc)
+        errs[tap] = (rel(h, h_ref), rel(U, U_ref), rel(W, W_ref))
+        if report is not None:
+            report.append((tap, errs[tap]))
+    bad = {k_: v for k_, v in errs.items() if max(v) >= tol or any(e != e for e in v)}
+    assert not bad, f"(primal, jvp, vjp) rel errors over tol {tol}: {bad}"
+    return errs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_toy_sd_primal_jvp_vjp(dtype):
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    f, cfg, p = _toy_sd()
+    net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=2, max_rank=8, verbose=False)
+    fwd = lambda a, tap: unet_sd.forward(p, cfg, a, f["t"], f["ctx"].expand(a.shape[0], -1, -1), stop=None if tap == "eps" else tap)
+    check_passes(net, fwd, f["z"], float(f["t"]), f["ctx"], [("down", 0), ("down", 1), ("mid", 0), ("up", 0), ("up", 1), "eps"], dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_ddpm_primal_jvp_vjp(dtype):
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_ddpm
+    f, cfg, p = _small_ddpm()
+    net = PullbackUNet("ddpm", cfg, p, dtype=dtype, device=_dev(), max_batch=2, max_rank=8, verbose=False)
+    fwd = lambda a, tap: unet_ddpm.forward(p, cfg, a, f["t"], stop=None if tap == "eps" else tap)
+    check_passes(net, fwd, f["x"], float(f["t"]), None,
+                 [("down", 0), ("down", 1), ("down", 2), ("mid", 0), ("up", 2), ("up", 1), ("up", 0), "eps"], dtype)
+
+
+def test_medium_sd_shapes_fp32():
+    """SD-like widths with the real head dims (40/80), 77-token context (padded to 80), 128x128 GEMM tiles."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=32, ctx_len=77)
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 4, 32, 32, generator=g); ctx = torch.randn(1, 77, 768, generator=g); t = torch.tensor(696.2727)
+    net = PullbackUNet("sd", cfg, p, dtype=torch.float32, device=_dev(), max_batch=1, max_rank=4, upto=("mid", 0), verbose=False)
+    fwd = lambda a, tap: unet_sd.forward(p, cfg, a, t, ctx.expand(a.shape[0], -1, -1), stop=tap)
+    check_passes(net, fwd, z, float(t), ctx, [("down", 0), ("mid", 0)], torch.float32, k=2)
+
+
+def test_ddpm_forward_matches_reference_golden():
+    """HIP eps / get_h against the vendored reference's own outputs (golden fixture), batch 1 and 2."""
+    from diffusion_pullback_amd import PullbackUNet
+    f, cfg, p = _small_ddpm()
+    net = PullbackUNet("ddpm", cfg, p, dtype=torch.float32, device=_dev(), max_batch=2, max_rank=4, verbose=False)
+    for op, idx in [("down", 0), ("down", 1), ("down", 2), ("mid", 0), ("up", 2), ("up", 1), ("up", 0)]:
+        h = net.get_h(x=f["x"], t=f["t"], op=op, block_idx=idx).cpu()
+        assert rel(h, f[f"h_{op}_{idx}"]) < 2e-4, (op, idx, rel(h, f[f"h_{op}_{idx}"]))
+    assert rel(net(f["x"], f["t"]).cpu(), f["eps"]) < 2e-4
+    assert rel(net(f["xb"], f["t"]).cpu(), f["eps_b"]) < 2e-4
+    with pytest.raises(ValueError):
+        net.get_h(x=f["x"], t=f["t"], op="down", block_idx=7)
+
+
+def test_orth_matches_svd():
+    from diffusion_pullback_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(4)
+    for k, n in [(1, 64), (3, 1000), (5, 16384), (10, 196608), (16, 4099)]:
+        scale = torch.logspace(0, -2, k)[:, None]
+        W = (torch.randn(k, k, generator=g) @ (scale * torch.linalg.qr(torch.randn(n, k, generator=g))[0].T)).float()
+        Vp = torch.linalg.qr(torch.randn(n, k, generator=g))[0].T.contiguous().float()
+        _, s_ref, V_ref = torch.linalg.svd(W.double(), full_matrices=False)
+        Wd, Vpd = W.cuda(), Vp.cuda()
+        V = torch.empty_like(Wd); s = torch.empty(k, device="cuda"); conv = torch.empty(2, device="cuda")
+        scratch = torch.empty(3 * k * k + 2, dtype=torch.float64, device="cuda")
+        L.check(lib.dpb_orth(Wd.data_ptr(), Vpd.data_ptr(), V.data_ptr(), s.data_ptr(), conv.data_ptr(), scratch.data_ptr(), k, n,
+                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        V = V.cpu().double()
+        assert torch.allclose(s.cpu().double(), s_ref.sqrt(), rtol=1e-4), (k, n, s.cpu(), s_ref.sqrt())
+        assert (abs_cos(V, V_ref) > 1 - 1e-5).all(), (k, n, abs_cos(V, V_ref))
+        assert torch.allclose(V @ V.T, torch.eye(k, dtype=torch.float64), atol=1e-4)
+        assert ((V * Vp.double()).sum(-1) >= -1e-6).all()          # sign convention: overlap with V_prev >= 0
+        assert abs(conv[0].item() - torch.dist(V.float(), Vp).item()) < 1e-3
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_pullback_zt_matches_reference_golden(case):
+    """End to end through the drop-in method vs the reference's own local_encoder_pullback_zt output."""
+    from diffusion_pullback_amd import PullbackUNet
+    f, cfg, p = _toy_sd()
+    c = f["cases"][case]
+    net = PullbackUNet("sd", cfg, p, dtype=torch.float32, device=_dev(), max_batch=1, max_rank=8, verbose=False)
+    u, s, vT = net.local_encoder_pullback_zt(f["z"], f["t"], f["ctx"], op=c["op"], block_idx=c["idx"], pca_rank=c["k"],
+                                             chunk_size=c["chunk"], min_iter=c["min_iter"], max_iter=c["max_iter"],
+                                             convergence_threshold=c["thr"], V0=c["V0"])
+    ur, sr, vr = c["zt"]
+    assert u.shape == ur.shape and vT.shape == vr.shape and s.shape == sr.shape
+    assert not u.is_contiguous()                              # transposed view like the reference (utils.py:810)
+    assert torch.allclose(s.cpu(), sr, rtol=2e-3), (s.cpu(), sr)
+    assert (abs_cos(vT, vr) > 0.999).all(), abs_cos(vT, vr)
+    assert (abs_cos(u.T, ur.T) > 0.999).all(), abs_cos(u.T, ur.T)
+
+
+def test_pullback_xt_matches_reference_golden():
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_ddpm
+    f = load_golden("pullback_xt_ddpm.pt")
+    cfg = unet_ddpm.DDPMConfig(**f["cfg"])
+    p = unet_ddpm.init_params(cfg, seed=f["seed"])
+    net = PullbackUNet("ddpm", cfg, p, dtype=torch.float32, device=_dev(), max_batch=1, max_rank=4, verbose=False)
+    u, s, vT = net.local_encoder_pullback_xt(f["x"], f["t"], op="mid", block_idx=0, pca_rank=f["k"], chunk_size=f["chunk_size"],
+                                             min_iter=f["min_iter"], max_iter=f["max_iter"], convergence_threshold=f["thr"], V0=f["V0"])
+    assert torch.allclose(s.cpu(), f["s"], rtol=2e-3), (s.cpu(), f["s"])
+    assert (abs_cos(vT, f["vT"]) > 0.999).all(), abs_cos(vT, f["vT"])
+    assert (abs_cos(u.T, f["u"].T) > 0.999).all()
