@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Headline benchmark: pullback top-k SVD power iterations / second (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one power iteration for k directions on one x_t sample: k JVPs + k VJPs through the
+U-Net prefix up to the tap + the k x N re-orthonormalisation (reference src/utils/utils.py:756-808).
+A sample's job is one primal (stash) pass + ITERS_PER_SAMPLE=12 iterations (= min_iter+2, the
+reference's minimum and what its Colab log ran); the primal pass of every sample started inside the
+timed region is timed too.  Inputs (x_t, ctx, V0) are resident in HBM before the clock starts.
+
+N>1: one process per GPU (torchrun), independent samples per rank (weak scaling, no data-path
+collective), one RCCL all_gather of the final bases (u, s, vT) inside the timed region.
+
+Output: ONE JSON line on rank 0 with `roofline` (dominant kernel = the 128x128 MFMA GEMM, measured live
+with HIP events around every launch in a separate instrumented iteration) and `cpu_baseline` (the CPU
+oracle, i.e. the reference's algorithm with the same autodiff calls, timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ITERS_PER_SAMPLE = 12
+PEAK = {"bf16": 2500.0, "fp32": 157.3}      # TFLOP/s dense MFMA (MI355X_MICROARCH.md)
+MAC_G = {"sd15": 130.72, "ddpm256": 67.58}  # GMAC of one get_h(mid) forward
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--workload", default="sd15", choices=["sd15", "ddpm256", "toy"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-k", type=int, default=None, help="directions for the CPU sample (default: k)")
+    return ap.parse_args()
+
+
+def make_workload(name, dtype, device, k, seed_base):
+    """-> (net, get_h_oracle, samples x [S,...], t, ctx, V0[k,N], tap)"""
+    from diffusion_pullback_amd import PullbackUNet
+    g = torch.Generator().manual_seed(0)
+    if name == "sd15" or name == "toy":
+        from diffusion_pullback_amd import configs as cf
+        cfg = cf.SD15 if name == "sd15" else cf.SDConfig(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False),
+                                                                  up_attn=(False, True), heads=(2, 2), cross_dim=64, sample_size=16, ctx_len=77)
+        enc = ("time_embedding", "conv_in", "down_blocks", "mid_block")
+        params = cf.sd_init_params(cfg, seed=0, only_prefix=enc)
+        net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=1, max_rank=k, upto=("mid", 0), verbose=False)
+        t = 696.2727
+        ctx = torch.randn(1, cfg.ctx_len, cfg.cross_dim, generator=g)          # fixed seeded "null" embedding
+        shape = (cfg.in_channels, cfg.sample_size, cfg.sample_size)
+        def oracle_get_h(zb):      # cpu_baseline leg only
+            from oracle import unet_sd
+            return unet_sd.forward(params, cfg, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=("mid", 0))
+    else:
+        from diffusion_pullback_amd import configs as cf
+        cfg = cf.CELEBA_HQ_256
+        params = cf.ddpm_init_params(cfg, seed=0)
+        net = PullbackUNet("ddpm", cfg, params, dtype=dtype, device=device, max_batch=1, max_rank=k, upto=("mid", 0), verbose=False)
+        t, ctx = 600.0, None
+        shape = (cfg.in_channels, cfg.resolution, cfg.resolution)
+        def oracle_get_h(xb):      # cpu_baseline leg only
+            from oracle import unet_ddpm
+            return unet_ddpm.forward(params, cfg, xb, torch.tensor(t), stop=("mid", 0))
+    n_in = shape[0] * shape[1] * shape[2]
+    V0 = torch.linalg.qr(torch.randn(n_in, k, generator=g))[0].T.contiguous()
+    return net, oracle_get_h, shape, t, ctx, V0
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dname = a.dtype or ("fp32" if a.workload == "ddpm256" else "bf16")
+    dtype = torch.float32 if dname == "fp32" else torch.bfloat16
+    k = a.k
+    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, rank)
+    tap = ("mid", 0)
+    eng = net.engine
+
+    n_samples = (a.steps + ITERS_PER_SAMPLE - 1) // ITERS_PER_SAMPLE
+    n_warm = (a.warmup + ITERS_PER_SAMPLE - 1) // ITERS_PER_SAMPLE if a.warmup > 0 else 0
+    gx = torch.Generator().manual_seed(1000 + rank)
+    xs = torch.randn(max(n_samples, n_warm, 1), *shape, generator=gx).to(dev)     # synthetic latents, resident in HBM
+    ctx_d = ctx.to(dev) if ctx is not None else None
+    V0_d = V0.to(dev)
+
+    def run(steps, xs_):
+        out = None
+        done = 0
+        si = 0
+        while done < steps:
+            n = min(ITERS_PER_SAMPLE, steps - done)
+            eng.primal(xs_[si:si + 1], t, ctx_d, tap)
+            V = V0_d.clone()
+            out = eng.iterate(tap, V, n)
+            done += n
+            si += 1
+        return out
+
+    if a.warmup > 0:
+        run(a.warmup, xs)
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    V, U, s, conv = run(a.steps, xs)
+    if dist:   # final basis gather (the only collective of the path)
+        for ten in (U, s, V):
+            buf = [torch.empty_like(ten) for _ in range(world)]
+            dist.all_gather(buf, ten.contiguous())
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist:
+        td = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = td.item()
+    finite = bool(torch.isfinite(s).all() and torch.isfinite(V).all())
+
+    res = {
+        "metric": "pullback top-k SVD iters/sec (SD-v1.5 mid-block, 4x64x64)" if a.workload == "sd15" else f"pullback top-k SVD iters/sec ({a.workload} mid-block)",
+        "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dname, "data": "synthetic (seeded random-init weights at the exact architecture shapes, randn latents)",
+        "config": {"workload": {"sd15": "BASELINE configs[2]: SD-v1.5 4x64x64 latent, no edit prompt (seeded null ctx[1,77,768]), mid-block h[1280,8,8], t=696.27",
+                                "ddpm256": "BASELINE configs[1]: CelebA-HQ DDPM 256x256 x[3,256,256], mid-block h[512,8,8], t=600",
+                                "toy": "toy SD-style net (plumbing check)"}[a.workload],
+                   "pca_rank": k, "iters_per_sample": ITERS_PER_SAMPLE, "samples_per_gpu": n_samples,
+                   "parallelism": f"{world} x independent samples, final all_gather of (u,s,vT)" if world > 1 else "single GPU"},
+        "finite": finite, "s_top": [round(v, 5) for v in s.cpu().tolist()],
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # ---- roofline leg: one instrumented iteration, HIP events around every GEMM launch on the engine stream
+        eng.primal(xs[0:1], t, ctx_d, tap)
+        eng.profile(True)
+        eng.iterate(tap, V0_d.clone(), 1)
+        n_big, ms_big, fl_big = eng.profile_read(True)
+        n_small, ms_small, fl_small = eng.profile_read(False)
+        eng.profile(False)
+        ach = fl_big / (ms_big * 1e-3) / 1e12 if ms_big > 0 else 0.0
+        mac = MAC_G.get(a.workload)
+        res["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dname},128,128>", "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s",
+                           "frac": ach / PEAK[dname], "traffic": None,
+                           "launches_per_iter": n_big, "avg_launch_us": 1e3 * ms_big / max(n_big, 1), "flops_per_iter": fl_big,
+                           "small_tile": {"kernel": f"gemm_kernel<{dname},64,64>", "launches_per_iter": n_small, "avg_launch_us": 1e3 * ms_small / max(n_small, 1),
+                                          "achieved": fl_small / (ms_small * 1e-3) / 1e12 if ms_small > 0 else 0.0},
+                           "gemm_time_share_of_step": (ms_big + ms_small) / res["ms_per_step"],
+                           "algorithmic_flops_per_step": 2 * k * 2 * mac * 1e9 if mac else None,
+                           "whole_step_frac_of_peak": (2 * k * 2 * mac * 1e9 / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK[dname]) if mac else None}
+
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference) on the host cores
+        from oracle import pullback as opb
+        ck = a.cpu_k or k
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        x_cpu = xs[0:1].cpu()
+        Vc = V0[:ck].reshape(ck, *shape)
+        tc0 = time.perf_counter()
+        u_c = opb.jvp_step(oracle_get_h, x_cpu, Vc, ck, 5 if a.workload != "ddpm256" else 25, "zt" if a.workload != "ddpm256" else "xt")
+        w_c = opb.vjp_step(oracle_get_h, x_cpu, u_c)
+        torch.linalg.svd(w_c, full_matrices=False)
+        tc = time.perf_counter() - tc0
+        res["cpu_baseline"] = {"value": (ck / k) / tc, "unit": "iters/s", "cores": cores, "kind": "port",
+                               "sample": f"1 power iteration (k={ck} of {k} directions; JVP+VJP+SVD, fp32) of the same workload, no warm-up, {tc:.1f}s"
+                                         + ("" if ck == k else f", scaled by {ck}/{k}")}
+        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,221 @@
+"""Network configurations and seeded synthetic weights for the two U-Net families of the pullback path.
+
+No checkpoints or datasets are reachable offline, so throughput runs and tests use random-init weights
+at the exact architecture shapes, generated on the CPU generator (identical bits for the HIP engine and
+for the CPU oracle).  Parameter names equal the upstream ``state_dict`` keys (vendored DDPM:
+reference src/models/ddpm/diffusion.py:22-129; SD: diffusers UNet2DConditionModel), so real weights
+drop in unchanged.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass(frozen=True)
+class DDPMConfig:
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4, 4)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = (16,)
+    in_channels: int = 3
+    out_ch: int = 3
+    resolution: int = 256
+    groups: int = 32
+    gn_eps: float = 1e-6
+
+    @property
+    def temb_ch(self) -> int:
+        return self.ch * 4
+
+
+# configs/custom_celeba_ddpm.yml:21-30
+CELEBA_HQ_256 = DDPMConfig()
+
+
+
+@dataclass(frozen=True)
+class SDConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    down_attn: Tuple[bool, ...] = (True, True, True, False)
+    up_attn: Tuple[bool, ...] = (False, True, True, True)
+    heads: Tuple[int, ...] = (8, 8, 8, 8)          # per down block; mid uses heads[-1]
+    cross_dim: int = 768
+    groups: int = 32
+    sample_size: int = 64
+    use_linear_projection: bool = False            # SD-2.x stores proj_in/out as Linear
+    ctx_len: int = 77
+
+    @property
+    def temb_ch(self) -> int:
+        return self.block_out_channels[0] * 4
+
+
+SD15 = SDConfig()
+
+
+
+def ddpm_param_shapes(cfg: DDPMConfig) -> Dict[str, Tuple[int, ...]]:
+    """Names/shapes of every parameter (equals the vendored module's state_dict layout)."""
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(n, i, o):
+        s[n + ".weight"] = (o, i); s[n + ".bias"] = (o,)
+
+    def conv(n, i, o, k):
+        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
+
+    def gn(n, c):
+        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
+
+    def resblock(n, i, o):
+        gn(n + ".norm1", i); conv(n + ".conv1", i, o, 3); lin(n + ".temb_proj", cfg.temb_ch, o)
+        gn(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".nin_shortcut", i, o, 1)
+
+    def attn(n, c):
+        gn(n + ".norm", c)
+        for w in ("q", "k", "v", "proj_out"):
+            conv(n + "." + w, c, c, 1)
+
+    lin("temb.dense.0", cfg.ch, cfg.temb_ch); lin("temb.dense.1", cfg.temb_ch, cfg.temb_ch)
+    conv("conv_in", cfg.in_channels, cfg.ch, 3)
+    nres = len(cfg.ch_mult)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    res = cfg.resolution
+    bi = cfg.ch
+    for lvl in range(nres):
+        bi, bo = cfg.ch * in_mult[lvl], cfg.ch * cfg.ch_mult[lvl]
+        for blk in range(cfg.num_res_blocks):
+            resblock(f"down.{lvl}.block.{blk}", bi, bo)
+            bi = bo
+            if res in cfg.attn_resolutions:
+                attn(f"down.{lvl}.attn.{blk}", bi)
+        if lvl != nres - 1:
+            conv(f"down.{lvl}.downsample.conv", bi, bi, 3)
+            res //= 2
+    resblock("mid.block_1", bi, bi); attn("mid.attn_1", bi); resblock("mid.block_2", bi, bi)
+    for lvl in reversed(range(nres)):
+        bo = cfg.ch * cfg.ch_mult[lvl]
+        skip = bo
+        for blk in range(cfg.num_res_blocks + 1):
+            if blk == cfg.num_res_blocks:
+                skip = cfg.ch * in_mult[lvl]
+            resblock(f"up.{lvl}.block.{blk}", bi + skip, bo)
+            bi = bo
+            if res in cfg.attn_resolutions:
+                attn(f"up.{lvl}.attn.{blk}", bi)
+        if lvl != 0:
+            conv(f"up.{lvl}.upsample.conv", bi, bi, 3)
+            res *= 2
+    gn("norm_out", bi); conv("conv_out", bi, cfg.out_ch, 3)
+    return s
+
+
+def ddpm_init_params(cfg: DDPMConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32) -> Params:
+    """Seeded synthetic weights (no checkpoints are reachable offline).
+
+    Fan-in scaled normal for matrices, GroupNorm affine near identity.  Generated on
+    CPU so the oracle and the HIP engine see identical bits."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shp in ddpm_param_shapes(cfg).items():
+        if name.endswith(".weight") and len(shp) == 1:          # norm gamma
+            p[name] = (1.0 + 0.1 * torch.randn(shp, generator=g)).to(dtype)
+        elif name.endswith(".bias"):
+            p[name] = (0.05 * torch.randn(shp, generator=g)).to(dtype)
+        else:
+            fan_in = math.prod(shp[1:])
+            p[name] = (gain * torch.randn(shp, generator=g) / math.sqrt(fan_in)).to(dtype)
+    return p
+
+
+def sd_param_shapes(cfg: SDConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(n, i, o, bias=True):
+        s[n + ".weight"] = (o, i)
+        if bias:
+            s[n + ".bias"] = (o,)
+
+    def conv(n, i, o, k):
+        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
+
+    def norm(n, c):
+        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
+
+    def resnet(n, i, o):
+        norm(n + ".norm1", i); conv(n + ".conv1", i, o, 3); lin(n + ".time_emb_proj", cfg.temb_ch, o)
+        norm(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1)
+
+    def attn(n, c, kv):
+        lin(n + ".to_q", c, c, False); lin(n + ".to_k", kv, c, False); lin(n + ".to_v", kv, c, False)
+        lin(n + ".to_out.0", c, c)
+
+    def transformer(n, c):
+        norm(n + ".norm", c)
+        if cfg.use_linear_projection:
+            lin(n + ".proj_in", c, c); lin(n + ".proj_out", c, c)
+        else:
+            conv(n + ".proj_in", c, c, 1); conv(n + ".proj_out", c, c, 1)
+        tb = n + ".transformer_blocks.0"
+        norm(tb + ".norm1", c); attn(tb + ".attn1", c, c)
+        norm(tb + ".norm2", c); attn(tb + ".attn2", c, cfg.cross_dim)
+        norm(tb + ".norm3", c); lin(tb + ".ff.net.0.proj", c, 8 * c); lin(tb + ".ff.net.2", 4 * c, c)
+
+    boc = cfg.block_out_channels
+    nb = len(boc)
+    lin("time_embedding.linear_1", boc[0], cfg.temb_ch); lin("time_embedding.linear_2", cfg.temb_ch, cfg.temb_ch)
+    conv("conv_in", cfg.in_channels, boc[0], 3)
+    ch = boc[0]
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{i}.resnets.{j}", ch, boc[i]); ch = boc[i]
+            if cfg.down_attn[i]:
+                transformer(f"down_blocks.{i}.attentions.{j}", ch)
+        if i != nb - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", ch, ch, 3)
+    resnet("mid_block.resnets.0", ch, ch); transformer("mid_block.attentions.0", ch); resnet("mid_block.resnets.1", ch, ch)
+    rev = tuple(reversed(boc))
+    prev = rev[0]
+    for i in range(nb):
+        out = rev[i]
+        inp = rev[min(i + 1, nb - 1)]
+        for j in range(cfg.layers_per_block + 1):
+            skip = inp if j == cfg.layers_per_block else out
+            rin = prev if j == 0 else out
+            resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, out)
+            if cfg.up_attn[i]:
+                transformer(f"up_blocks.{i}.attentions.{j}", out)
+        if i != nb - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", out, out, 3)
+        prev = out
+    norm("conv_norm_out", boc[0]); conv("conv_out", boc[0], cfg.out_channels, 3)
+    return s
+
+
+def sd_init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32, only_prefix=None) -> Params:
+    """Seeded synthetic weights at the exact architecture shapes (CPU generator)."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shp in sd_param_shapes(cfg).items():
+        if name.endswith(".weight") and len(shp) == 1:
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g)
+        else:
+            t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
+        if only_prefix is None or name.startswith(only_prefix):
+            p[name] = t.to(dtype)
+    return p

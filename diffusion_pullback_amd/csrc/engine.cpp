@@ -38,7 +38,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 static inline int round8(int v) { return (v + 7) / 8 * 8; }
 
 struct Buf {
-  int rows = 0, C = 0, kind = 0;
+  int rows = 0, C = 0, kind = 0, Cv = 0;   // Cv: valid (un-padded) channels
   bool is_const = true;      // independent of x
   size_t p_off = 0, t_off = 0, g_off = 0;
 };
@@ -80,6 +80,10 @@ struct dpb_engine {
   std::vector<char> ginit;
   long n_launch = 0;
   double flops = 0, gbytes = 0;
+  // optional per-launch timing of the GEMM kernel (bench.py roofline leg); off in the timed region
+  bool profiling = false;
+  struct Prof { hipEvent_t a, b; double flops; int big; };
+  std::vector<Prof> prof;
 
   char* P(int b) const { return ws + bufs[b].p_off; }
   char* T(int b) const { return ws + bufs[b].t_off; }
@@ -100,7 +104,17 @@ int gemm(dpb_engine* e, const GemmArgs& a) {
   e->n_launch++;
   e->flops += 2.0 * a.M * (double)a.N * a.K * a.Z1 * a.Z2;
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
-  return launch_gemm(e->dtype, a, e->stream);
+  if (!e->profiling) return launch_gemm(e->dtype, a, e->stream);
+  dpb_engine::Prof p;
+  p.flops = 2.0 * a.M * (double)a.N * a.K * a.Z1 * a.Z2;
+  p.big = gemm_uses_big_tile(a);
+  DPB_CHECK(hipEventCreate(&p.a));
+  DPB_CHECK(hipEventCreate(&p.b));
+  DPB_CHECK(hipEventRecord(p.a, e->stream));
+  int r = launch_gemm(e->dtype, a, e->stream);
+  DPB_CHECK(hipEventRecord(p.b, e->stream));
+  e->prof.push_back(p);
+  return r;
 }
 
 // ------------------------------------------------------------------ CONV
@@ -492,6 +506,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
     e->bufs[i].rows = net->buffers[i].rows;
     e->bufs[i].C = net->buffers[i].channels;
     e->bufs[i].kind = net->buffers[i].kind;
+    e->bufs[i].Cv = net->buffers[i].valid_channels > 0 ? net->buffers[i].valid_channels : net->buffers[i].channels;
     if (e->bufs[i].rows < 1 || e->bufs[i].C < 8 || e->bufs[i].C % 8) { fail("buffer %d: rows=%d channels=%d (channels must be a multiple of 8)", i, e->bufs[i].rows, e->bufs[i].C); delete e; return -1; }
   }
   if (net->x_buf < 0 || net->x_buf >= nb) { fail("bad x_buf"); delete e; return -1; }
@@ -681,7 +696,7 @@ int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
   }
   const Buf& bt = e->bufs[tap];
   e->n_launch++;
-  return launch_nhwc_to_nchw(e->dtype, e->T(tap), U, nt, bt.C, bt.rows, bt.C, e->stream);
+  return launch_nhwc_to_nchw(e->dtype, e->T(tap), U, nt, bt.Cv, bt.rows, bt.C, e->stream);
 }
 
 int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
@@ -691,7 +706,7 @@ int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   const Buf& bt = e->bufs[tap];
   std::fill(e->ginit.begin(), e->ginit.end(), 0);
   e->n_launch++;
-  if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.C, bt.rows, bt.C, e->stream)) return r;
+  if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
   e->ginit[tap] = 1;
   if (e->tstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
   for (int i = e->producer[tap]; i >= 0; --i) {
@@ -742,6 +757,27 @@ int dpb_ddim_step(const float* x, const float* eps, float* out, float* x0, int64
 int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int64_t n, float a, float b, float c, void* stream) {
   if (!x || !y || !out) return fail("null argument");
   return launch_lincomb(x, y, z, out, n, a, b, c, (hipStream_t)stream);
+}
+
+int dpb_engine_profile(dpb_engine* e, int enable) {
+  if (!e) return fail("null engine");
+  for (auto& p : e->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  e->prof.clear();
+  e->profiling = enable != 0;
+  return 0;
+}
+
+int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double* total_ms, double* flops) {
+  if (!e || !count || !total_ms || !flops) return fail("null argument");
+  DPB_CHECK(hipStreamSynchronize(e->stream));
+  *count = 0; *total_ms = 0; *flops = 0;
+  for (auto& p : e->prof) {
+    if (p.big != big_tile) continue;
+    float ms = 0;
+    DPB_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+    *count += 1; *total_ms += ms; *flops += p.flops;
+  }
+  return 0;
 }
 
 int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes) {

@@ -241,6 +241,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
+int gemm_uses_big_tile(const GemmArgs& a) {
+  long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
+  return t128 >= 192 && a.N > 64;
+}
+
 template <typename T>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
@@ -250,8 +255,7 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
   }
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K); return -1; }
   const int Z = a.Z1 * a.Z2;
-  long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * Z;
-  if (t128 >= 192 && a.N > 64) {
+  if (gemm_uses_big_tile(a)) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z);
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
   } else {

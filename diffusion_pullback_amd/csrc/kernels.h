@@ -26,6 +26,7 @@ struct GemmArgs {
   int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, KS = 1, stride = 1, pad = 0;
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+int gemm_uses_big_tile(const GemmArgs& a);   // 1: 128x128 tile instantiation, 0: 64x64
 
 // ---------------------------------------------------------------- normalisation
 enum { MODE_PRIMAL = 0, MODE_TANGENT = 1, MODE_ADJOINT = 2 };

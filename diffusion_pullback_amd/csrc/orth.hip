@@ -19,25 +19,26 @@ constexpr int KMAX = 16;
 // grid (nblk, k): block row i accumulates G[i][:] and X[i][:] = W_i . Vprev_j over a slice of N
 __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* Vp, double* G, double* X, int k, long N) {
   const int i = blockIdx.y;
-  float g[KMAX], x[KMAX];
+  double g[KMAX], x[KMAX];   // fp64 accumulation: small singular values survive the squaring in the Gram matrix
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) g[j] = x[j] = 0.f;
+  for (int j = 0; j < KMAX; ++j) g[j] = x[j] = 0.0;
   for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)gridDim.x * 256) {
-    const float wi = W[(long)i * N + n];
+    const double wi = W[(long)i * N + n];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
       if (j < k) {
-        g[j] += wi * W[(long)j * N + n];
-        x[j] += wi * Vp[(long)j * N + n];
+        g[j] += wi * (double)W[(long)j * N + n];
+        x[j] += wi * (double)Vp[(long)j * N + n];
       }
     }
   }
-  __shared__ float red[2][KMAX][4];
+  __shared__ double red[2][KMAX][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
     if (j < k) {
-      float a = wave_sum(g[j]), b = wave_sum(x[j]);
+      double a = g[j], b = x[j];
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
       if (lane == 0) { red[0][j][wave] = a; red[1][j][wave] = b; }
     }
   }
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* 
   if (threadIdx.x < 2 * KMAX) {
     int w = threadIdx.x / KMAX, j = threadIdx.x % KMAX;
     if (j < k) {
-      double s = (double)red[w][j][0] + red[w][j][1] + red[w][j][2] + red[w][j][3];
+      double s = red[w][j][0] + red[w][j][1] + red[w][j][2] + red[w][j][3];
       atomicAdd((w == 0 ? G : X) + i * k + j, s);
     }
   }

@@ -33,7 +33,7 @@ class Engine:
         self.max_batch, self.max_tangents = max_batch, max_tangents
         self.x_channels = x_channels
         nb, no = len(tape.buffers), len(tape.ops)
-        self._bufs = (L.BufferDesc * nb)(*[L.BufferDesc(r, c, k, 0) for (r, c, k) in tape.buffers])
+        self._bufs = (L.BufferDesc * nb)(*[L.BufferDesc(r, c, k, v) for (r, c, k), v in zip(tape.buffers, tape.valid)])
         ops = (L.OpDesc * no)()
         for i, d in enumerate(tape.ops):
             o = ops[i]
@@ -158,6 +158,14 @@ class Engine:
             conv = torch.empty(2, dtype=torch.float32, device=self.device)
             L.check(self.lib.dpb_pullback_iterate(self.h, buf, _ptr(V), _ptr(U), _ptr(s), _ptr(conv), k, n_iters))
         return V, U, s, conv
+
+    def profile(self, enable: bool):
+        L.check(self.lib.dpb_engine_profile(self.h, int(enable)))
+
+    def profile_read(self, big_tile: bool):
+        n = C.c_int64(); ms = C.c_double(); f = C.c_double()
+        L.check(self.lib.dpb_engine_profile_read(self.h, int(big_tile), C.byref(n), C.byref(ms), C.byref(f)))
+        return n.value, ms.value, f.value
 
     def stats(self):
         n = C.c_int64(); f = C.c_double(); b = C.c_double()

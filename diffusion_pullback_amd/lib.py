@@ -20,7 +20,7 @@ BUF_ACT, BUF_SHARED = 0, 1
 
 
 class BufferDesc(C.Structure):
-    _fields_ = [("rows", C.c_int32), ("channels", C.c_int32), ("kind", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("rows", C.c_int32), ("channels", C.c_int32), ("kind", C.c_int32), ("valid_channels", C.c_int32)]
 
 
 class OpDesc(C.Structure):
@@ -55,6 +55,8 @@ SYMBOLS = {
     "dpb_ddim_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
     "dpb_lincomb": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _P]),
     "dpb_engine_stats": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dpb_engine_profile": (_I, [_P, _I]),
+    "dpb_engine_profile_read": (_I, [_P, _I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

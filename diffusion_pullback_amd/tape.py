@@ -33,6 +33,7 @@ class Tape:
         self.dtype = dtype
         self.device = torch.device(device)
         self.buffers: List[Tuple[int, int, int]] = []
+        self.valid: List[int] = []
         self.ops: List[dict] = []
         self.keep: List[torch.Tensor] = []          # device weights (kept alive for the engine)
         self.taps: Dict[object, int] = {}
@@ -41,8 +42,9 @@ class Tape:
         self._wcache: Dict[str, Tuple[int, int, int]] = {}
 
     # ------------------------------------------------------------- buffers / weights
-    def buf(self, rows: int, ch: int, kind: int = L.BUF_ACT) -> int:
+    def buf(self, rows: int, ch: int, kind: int = L.BUF_ACT, valid: int = 0) -> int:
         self.buffers.append((rows, ch, kind))
+        self.valid.append(valid)
         return len(self.buffers) - 1
 
     def _dev(self, t: torch.Tensor, dtype) -> int:
@@ -91,7 +93,7 @@ class Tape:
             wo = (w + 2 * pad - ks) // stride + 1 if pad else (w + 1 - ks) // stride + 1
             gather = L.GATHER_CONV
         cout_p = _r8(cout)
-        out = self.buf(ho * wo if ks != 1 else rows, cout_p, kind)
+        out = self.buf(ho * wo if ks != 1 else rows, cout_p, kind, cout if cout != cout_p else 0)
         pf, pa, pb = self._conv_w(name, cin_p, cout_p, need_adj)
         self._op(kind=L.OP_CONV, in0=x, out=out, res=res, rowbias=rowbias,
                  ip=[h, w, cin_p, ho, wo, cout, ks, stride, pad, gather, 0, 0], w=[pf, pa, pb, 0])

@@ -47,7 +47,7 @@ typedef struct dpb_buffer_desc {
   int32_t rows;       /* H*W or token count, per sample */
   int32_t channels;   /* stored channel count (multiple of 8) */
   int32_t kind;       /* DPB_BUF_* */
-  int32_t reserved;
+  int32_t valid_channels; /* un-padded channel count seen at the fp32 NCHW boundary; 0 = channels */
 } dpb_buffer_desc;
 
 typedef struct dpb_op_desc {
@@ -129,6 +129,11 @@ int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int6
 
 /* Introspection used by tests / bench: number of kernel launches and algorithmic GEMM flops of the last pass. */
 int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes);
+/* Measurement aid (bench.py roofline leg, never on in a timed region): bracket every GEMM launch with HIP
+ * events on the engine's stream; _read synchronises and sums launches of the 128x128 (big_tile=1) or 64x64
+ * (big_tile=0) instantiation: count, total milliseconds, algorithmic flops. */
+int dpb_engine_profile(dpb_engine* e, int enable);
+int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double* total_ms, double* flops);
 
 #ifdef __cplusplus
 }

@@ -23,34 +23,14 @@ module's ``state_dict()`` keys, so a reference state_dict can be fed unchanged
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 
-Params = Dict[str, torch.Tensor]
-
-
-@dataclass(frozen=True)
-class DDPMConfig:
-    ch: int = 128
-    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4, 4)
-    num_res_blocks: int = 2
-    attn_resolutions: Tuple[int, ...] = (16,)
-    in_channels: int = 3
-    out_ch: int = 3
-    resolution: int = 256
-    groups: int = 32
-    gn_eps: float = 1e-6
-
-    @property
-    def temb_ch(self) -> int:
-        return self.ch * 4
-
-
-# configs/custom_celeba_ddpm.yml:21-30
-CELEBA_HQ_256 = DDPMConfig()
+from diffusion_pullback_amd.configs import CELEBA_HQ_256, DDPMConfig, Params  # noqa: F401  (shared config + synthetic weights)
+from diffusion_pullback_amd.configs import ddpm_init_params as init_params  # noqa: F401
+from diffusion_pullback_amd.configs import ddpm_param_shapes as param_shapes  # noqa: F401
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -148,79 +128,3 @@ def forward(p: Params, cfg: DDPMConfig, x: torch.Tensor, t, stop: Optional[Tuple
     if stop is not None:
         raise ValueError(f"(op, block_idx) = {stop} is not valid")
     return _conv(p, "conv_out", _swish(_gn(p, "norm_out", h, cfg)))
-
-
-def param_shapes(cfg: DDPMConfig) -> Dict[str, Tuple[int, ...]]:
-    """Names/shapes of every parameter (equals the vendored module's state_dict layout)."""
-    s: Dict[str, Tuple[int, ...]] = {}
-
-    def lin(n, i, o):
-        s[n + ".weight"] = (o, i); s[n + ".bias"] = (o,)
-
-    def conv(n, i, o, k):
-        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
-
-    def gn(n, c):
-        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
-
-    def resblock(n, i, o):
-        gn(n + ".norm1", i); conv(n + ".conv1", i, o, 3); lin(n + ".temb_proj", cfg.temb_ch, o)
-        gn(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
-        if i != o:
-            conv(n + ".nin_shortcut", i, o, 1)
-
-    def attn(n, c):
-        gn(n + ".norm", c)
-        for w in ("q", "k", "v", "proj_out"):
-            conv(n + "." + w, c, c, 1)
-
-    lin("temb.dense.0", cfg.ch, cfg.temb_ch); lin("temb.dense.1", cfg.temb_ch, cfg.temb_ch)
-    conv("conv_in", cfg.in_channels, cfg.ch, 3)
-    nres = len(cfg.ch_mult)
-    in_mult = (1,) + tuple(cfg.ch_mult)
-    res = cfg.resolution
-    bi = cfg.ch
-    for lvl in range(nres):
-        bi, bo = cfg.ch * in_mult[lvl], cfg.ch * cfg.ch_mult[lvl]
-        for blk in range(cfg.num_res_blocks):
-            resblock(f"down.{lvl}.block.{blk}", bi, bo)
-            bi = bo
-            if res in cfg.attn_resolutions:
-                attn(f"down.{lvl}.attn.{blk}", bi)
-        if lvl != nres - 1:
-            conv(f"down.{lvl}.downsample.conv", bi, bi, 3)
-            res //= 2
-    resblock("mid.block_1", bi, bi); attn("mid.attn_1", bi); resblock("mid.block_2", bi, bi)
-    for lvl in reversed(range(nres)):
-        bo = cfg.ch * cfg.ch_mult[lvl]
-        skip = bo
-        for blk in range(cfg.num_res_blocks + 1):
-            if blk == cfg.num_res_blocks:
-                skip = cfg.ch * in_mult[lvl]
-            resblock(f"up.{lvl}.block.{blk}", bi + skip, bo)
-            bi = bo
-            if res in cfg.attn_resolutions:
-                attn(f"up.{lvl}.attn.{blk}", bi)
-        if lvl != 0:
-            conv(f"up.{lvl}.upsample.conv", bi, bi, 3)
-            res *= 2
-    gn("norm_out", bi); conv("conv_out", bi, cfg.out_ch, 3)
-    return s
-
-
-def init_params(cfg: DDPMConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32) -> Params:
-    """Seeded synthetic weights (no checkpoints are reachable offline).
-
-    Fan-in scaled normal for matrices, GroupNorm affine near identity.  Generated on
-    CPU so the oracle and the HIP engine see identical bits."""
-    g = torch.Generator().manual_seed(seed)
-    p: Params = {}
-    for name, shp in param_shapes(cfg).items():
-        if name.endswith(".weight") and len(shp) == 1:          # norm gamma
-            p[name] = (1.0 + 0.1 * torch.randn(shp, generator=g)).to(dtype)
-        elif name.endswith(".bias"):
-            p[name] = (0.05 * torch.randn(shp, generator=g)).to(dtype)
-        else:
-            fan_in = math.prod(shp[1:])
-            p[name] = (gain * torch.randn(shp, generator=g) / math.sqrt(fan_in)).to(dtype)
-    return p

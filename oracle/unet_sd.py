@@ -24,36 +24,14 @@ when present.  Anchors: parameter count 859,520,964 (tests/test_oracle.py).
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 
-Params = Dict[str, torch.Tensor]
-
-
-@dataclass(frozen=True)
-class SDConfig:
-    in_channels: int = 4
-    out_channels: int = 4
-    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
-    layers_per_block: int = 2
-    down_attn: Tuple[bool, ...] = (True, True, True, False)
-    up_attn: Tuple[bool, ...] = (False, True, True, True)
-    heads: Tuple[int, ...] = (8, 8, 8, 8)          # per down block; mid uses heads[-1]
-    cross_dim: int = 768
-    groups: int = 32
-    sample_size: int = 64
-    use_linear_projection: bool = False            # SD-2.x stores proj_in/out as Linear
-    ctx_len: int = 77
-
-    @property
-    def temb_ch(self) -> int:
-        return self.block_out_channels[0] * 4
-
-
-SD15 = SDConfig()
+from diffusion_pullback_amd.configs import SD15, Params, SDConfig  # noqa: F401  (shared config + synthetic weights)
+from diffusion_pullback_amd.configs import sd_init_params as init_params  # noqa: F401
+from diffusion_pullback_amd.configs import sd_param_shapes as param_shapes  # noqa: F401
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -162,85 +140,3 @@ def forward(p: Params, cfg: SDConfig, x, t, ctx, stop: Optional[Tuple[str, int]]
     if stop is not None:
         raise ValueError(f"(op, block_idx) = {stop} is not valid")
     return _conv(p, "conv_out", F.silu(_gn(p, "conv_norm_out", h, cfg.groups, 1e-5)))
-
-
-def param_shapes(cfg: SDConfig) -> Dict[str, Tuple[int, ...]]:
-    s: Dict[str, Tuple[int, ...]] = {}
-
-    def lin(n, i, o, bias=True):
-        s[n + ".weight"] = (o, i)
-        if bias:
-            s[n + ".bias"] = (o,)
-
-    def conv(n, i, o, k):
-        s[n + ".weight"] = (o, i, k, k); s[n + ".bias"] = (o,)
-
-    def norm(n, c):
-        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
-
-    def resnet(n, i, o):
-        norm(n + ".norm1", i); conv(n + ".conv1", i, o, 3); lin(n + ".time_emb_proj", cfg.temb_ch, o)
-        norm(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
-        if i != o:
-            conv(n + ".conv_shortcut", i, o, 1)
-
-    def attn(n, c, kv):
-        lin(n + ".to_q", c, c, False); lin(n + ".to_k", kv, c, False); lin(n + ".to_v", kv, c, False)
-        lin(n + ".to_out.0", c, c)
-
-    def transformer(n, c):
-        norm(n + ".norm", c)
-        if cfg.use_linear_projection:
-            lin(n + ".proj_in", c, c); lin(n + ".proj_out", c, c)
-        else:
-            conv(n + ".proj_in", c, c, 1); conv(n + ".proj_out", c, c, 1)
-        tb = n + ".transformer_blocks.0"
-        norm(tb + ".norm1", c); attn(tb + ".attn1", c, c)
-        norm(tb + ".norm2", c); attn(tb + ".attn2", c, cfg.cross_dim)
-        norm(tb + ".norm3", c); lin(tb + ".ff.net.0.proj", c, 8 * c); lin(tb + ".ff.net.2", 4 * c, c)
-
-    boc = cfg.block_out_channels
-    nb = len(boc)
-    lin("time_embedding.linear_1", boc[0], cfg.temb_ch); lin("time_embedding.linear_2", cfg.temb_ch, cfg.temb_ch)
-    conv("conv_in", cfg.in_channels, boc[0], 3)
-    ch = boc[0]
-    for i in range(nb):
-        for j in range(cfg.layers_per_block):
-            resnet(f"down_blocks.{i}.resnets.{j}", ch, boc[i]); ch = boc[i]
-            if cfg.down_attn[i]:
-                transformer(f"down_blocks.{i}.attentions.{j}", ch)
-        if i != nb - 1:
-            conv(f"down_blocks.{i}.downsamplers.0.conv", ch, ch, 3)
-    resnet("mid_block.resnets.0", ch, ch); transformer("mid_block.attentions.0", ch); resnet("mid_block.resnets.1", ch, ch)
-    rev = tuple(reversed(boc))
-    prev = rev[0]
-    for i in range(nb):
-        out = rev[i]
-        inp = rev[min(i + 1, nb - 1)]
-        for j in range(cfg.layers_per_block + 1):
-            skip = inp if j == cfg.layers_per_block else out
-            rin = prev if j == 0 else out
-            resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, out)
-            if cfg.up_attn[i]:
-                transformer(f"up_blocks.{i}.attentions.{j}", out)
-        if i != nb - 1:
-            conv(f"up_blocks.{i}.upsamplers.0.conv", out, out, 3)
-        prev = out
-    norm("conv_norm_out", boc[0]); conv("conv_out", boc[0], cfg.out_channels, 3)
-    return s
-
-
-def init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32, only_prefix=None) -> Params:
-    """Seeded synthetic weights at the exact architecture shapes (CPU generator)."""
-    g = torch.Generator().manual_seed(seed)
-    p: Params = {}
-    for name, shp in param_shapes(cfg).items():
-        if name.endswith(".weight") and len(shp) == 1:
-            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
-        elif name.endswith(".bias"):
-            t = 0.05 * torch.randn(shp, generator=g)
-        else:
-            t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
-        if only_prefix is None or name.startswith(only_prefix):
-            p[name] = t.to(dtype)
-    return p
