@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-k", type=int, default=None, help="directions for the CPU sample (default: k)")
+    ap.add_argument("--cpu-k", type=int, default=1, help="directions in the bounded CPU sample (scaled to k; 0 = all k)")
     return ap.parse_args()
 
 
@@ -159,6 +159,8 @@ def main():
         eng.primal(xs[0:1], t, ctx_d, tap)
         eng.profile(True)
         eng.iterate(tap, V0_d.clone(), 1)
+        if os.environ.get("DPB_PROFILE_CSV"):
+            eng.profile_dump(os.environ["DPB_PROFILE_CSV"])
         n_big, ms_big, fl_big = eng.profile_read(True)
         n_small, ms_small, fl_small = eng.profile_read(False)
         eng.profile(False)
@@ -176,8 +178,8 @@ def main():
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference) on the host cores
         from oracle import pullback as opb
-        ck = a.cpu_k or k
-        cores = os.cpu_count() or 1
+        ck = min(a.cpu_k, k) if a.cpu_k else k
+        cores = min(os.cpu_count() or 1, 32)      # torch CPU kernels stop scaling (and oversubscribe) far below 256 threads
         torch.set_num_threads(cores)
         x_cpu = xs[0:1].cpu()
         Vc = V0[:ck].reshape(ck, *shape)

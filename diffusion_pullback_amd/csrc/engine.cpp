@@ -73,7 +73,7 @@ struct dpb_engine {
   size_t ws_bytes = 0;
   // arena offsets
   size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0;
-  size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0;
+  size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20;
   size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
   size_t temb_host_stage = 0;
   int cur_batch = 0;
@@ -82,7 +82,7 @@ struct dpb_engine {
   double flops = 0, gbytes = 0;
   // optional per-launch timing of the GEMM kernel (bench.py roofline leg); off in the timed region
   bool profiling = false;
-  struct Prof { hipEvent_t a, b; double flops; int big; };
+  struct Prof { hipEvent_t a, b; double flops; int big; int M, N, K, Z, gather; };
   std::vector<Prof> prof;
 
   char* P(int b) const { return ws + bufs[b].p_off; }
@@ -100,14 +100,18 @@ int fail(const char* fmt, ...) {
   return -1;
 }
 
-int gemm(dpb_engine* e, const GemmArgs& a) {
+int gemm(dpb_engine* e, GemmArgs a) {
   e->n_launch++;
-  e->flops += 2.0 * a.M * (double)a.N * a.K * a.Z1 * a.Z2;
+  a.slab = (float*)(e->ws + e->slab);
+  a.slab_bytes = e->slab_bytes;
+  const double kk = (double)a.K + (a.A2 ? a.K2 : 0);
+  e->flops += 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
   if (!e->profiling) return launch_gemm(e->dtype, a, e->stream);
   dpb_engine::Prof p;
-  p.flops = 2.0 * a.M * (double)a.N * a.K * a.Z1 * a.Z2;
+  p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   p.big = gemm_uses_big_tile(a);
+  p.M = a.M; p.N = a.N; p.K = a.K; p.Z = a.Z1 * a.Z2; p.gather = a.gather;
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));
   DPB_CHECK(hipEventRecord(p.a, e->stream));
@@ -367,13 +371,12 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
   g.B = e->P(d.in1); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
   g.C = S1; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
   g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = nt; g.Z2 = H; g.alpha = scale;
-  if (int r = gemm(e, g)) return r;
-  if (!p.kv_const) {   // += scale * Q dK^T
-    g.A = e->P(d.in0); g.divA = kps;
-    g.B = e->T(d.in1); g.divB = 1;
-    g.accumulate = 1;
-    if (int r = gemm(e, g)) return r;
+  if (!p.kv_const) {   // + scale * Q dK^T in the same launch (second operand pair)
+    g.A2 = e->P(d.in0); g.lda2 = C; g.sA21 = (long)p.Lq * C; g.sA22 = p.d; g.divA2 = kps;
+    g.B2 = e->T(d.in1); g.ldb2 = C; g.sB21 = (long)p.Lk * C; g.sB22 = p.d; g.divB2 = 1;
+    g.K2 = p.d;
   }
+  if (int r = gemm(e, g)) return r;
   e->n_launch++;
   if (int r = launch_softmax_jvp(e->dtype, ws + p.P, S1, nullptr, (long)nt * H, H, kps, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
   GemmArgs o;   // dO = dP V
@@ -381,17 +384,15 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
   o.B = ws + p.VT; o.ldb = p.Lkp; o.sB1 = (long)H * p.d * p.Lkp; o.sB2 = (long)p.d * p.Lkp; o.divB = kps;
   o.C = e->T(d.out); o.ldc = C; o.sC1 = (long)p.Lq * C; o.sC2 = p.d;
   o.M = p.Lq; o.N = p.d; o.K = p.Lkp; o.Z1 = nt; o.Z2 = H;
-  if (int r = gemm(e, o)) return r;
-  if (!p.kv_const) {   // += P dV
+  if (!p.kv_const) {   // + P dV in the same launch
     char* T1 = ws + e->T1;
     e->n_launch++;
     if (int r = launch_transpose(e->dtype, e->T(d.in2), T1, nt, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
-    o.A = ws + p.P; o.divA = kps;
-    o.B = T1; o.divB = 1;
-    o.accumulate = 1;
-    if (int r = gemm(e, o)) return r;
+    o.A2 = ws + p.P; o.lda2 = p.Lkp; o.sA21 = (long)H * p.Lq * p.Lkp; o.sA22 = (long)p.Lq * p.Lkp; o.divA2 = kps;
+    o.B2 = T1; o.ldb2 = p.Lkp; o.sB21 = (long)H * p.d * p.Lkp; o.sB22 = (long)p.d * p.Lkp; o.divB2 = 1;
+    o.K2 = p.Lkp;
   }
-  return 0;
+  return gemm(e, o);
 }
 
 int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
@@ -601,6 +602,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   e->io_in = take(nio);
   e->io_out = take(nio);
   e->orth = take(sizeof(double) * (3 * 16 * 16 + 2));
+  e->slab = take(e->slab_bytes);
   const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
   e->pbV = 0; e->pbW = take((size_t)e->maxT * nx * sizeof(float)); e->pbVn = take((size_t)e->maxT * nx * sizeof(float));
   e->ws_bytes = off;
@@ -764,6 +766,22 @@ int dpb_engine_profile(dpb_engine* e, int enable) {
   for (auto& p : e->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   e->prof.clear();
   e->profiling = enable != 0;
+  return 0;
+}
+
+int dpb_engine_profile_dump(dpb_engine* e, const char* path) {
+  if (!e || !path) return fail("null argument");
+  DPB_CHECK(hipStreamSynchronize(e->stream));
+  FILE* f = fopen(path, "w");
+  if (!f) return fail("cannot open %s", path);
+  fprintf(f, "idx,big,gather,M,N,K,Z,us,tflops\n");
+  int i = 0;
+  for (auto& p : e->prof) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.2f\n", i++, p.big, p.gather, p.M, p.N, p.K, p.Z, ms * 1e3, ms > 0 ? p.flops / (ms * 1e-3) / 1e12 : 0.0);
+  }
+  fclose(f);
   return 0;
 }
 

@@ -1,6 +1,6 @@
 // MFMA GEMM / implicit-GEMM convolution for gfx950 (wave64).
 //
-//   C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k]  (+bias) (+rowbias) (+R) (+C)
+//   C[z][m][n] = alpha * ( sum_k A[z][m][k] B[z][n][k]  +  sum_k A2[z][m][k] B2[z][n][k] )  (+bias) (+rowbias) (+R) (+C)
 //
 // One kernel serves every dense contraction of the pullback path: 3x3 / strided /
 // transposed / upsampling convolutions (A rows gathered from NHWC pixels), 1x1
@@ -8,6 +8,8 @@
 // attention (two-level batch z = (tangent, head)).  Linear maps have identical
 // primal, tangent and (with the pre-transposed weight) adjoint kernels, so the
 // JVP batch and the VJP batch of the power iteration are both just larger M.
+// The optional second operand pair extends the K loop (dS = dQ K^T + Q dK^T and
+// dO = dP V + P dV are ONE launch each: no read-modify-write pass over the scores).
 //
 // Tiling: 256 threads = 4 waves (2x2); each wave owns (BM/2)x(BN/2) as 32x32 MFMA
 // tiles.  bf16: v_mfma_f32_32x32x16_bf16, LDS tiles row-major [rows][32+8] so a
@@ -15,12 +17,27 @@
 // [16][rows+4] so a fragment is one conflict-free ds_read_b32.  K advances 4
 // 16-byte chunks per step; global->register prefetch of step t+1 overlaps the MFMAs
 // of step t, LDS is double buffered (one barrier per step).
+// Epilogue: accumulators are staged through LDS (fp32) and leave as full 16/32-byte
+// row segments with bias / time-embedding row bias / residual / accumulate fused.
+// Small-M problems (8x8 feature maps: M = 64k rows) split K over blockIdx.z into
+// fp32 slabs that a second kernel reduces (weights stream from HBM exactly once).
+// Workgroup ids are remapped so that one XCD (= one L2) walks neighbouring tiles.
 #include "kernels.h"
 
 namespace dpb {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <typename T> struct V8;   // 8 consecutive elements <-> float[8]
+template <> struct V8<float> {
+  __device__ static inline void load(const float* p, float* o) { Vec<float>::load(p, o); Vec<float>::load(p + 4, o + 4); }
+  __device__ static inline void store(float* p, const float* o) { Vec<float>::store(p, o); Vec<float>::store(p + 4, o + 4); }
+};
+template <> struct V8<bf16> {
+  __device__ static inline void load(const bf16* p, float* o) { Vec<bf16>::load(p, o); }
+  __device__ static inline void store(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
+};
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -33,13 +50,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int B_ELEMS = F32 ? BK * LDB_S : BN * LDB_S;
   constexpr int NA = BM / 64, NB = BN / 64;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  __shared__ __attribute__((aligned(16))) T smem[2 * (A_ELEMS + B_ELEMS)];
-  T* As = smem;
-  T* Bs = smem + 2 * A_ELEMS;
+  constexpr int SLD = WN + 4;                                   // stage row stride (floats)
+  constexpr int MAIN_BYTES = 2 * (A_ELEMS + B_ELEMS) * (int)sizeof(T);
+  constexpr int STAGE_BYTES = 4 * 32 * SLD * 4;
+  constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Bs = As + 2 * A_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tilesN = (p.N + BN - 1) / BN;
-  const int tm_i = blockIdx.x / tilesN, tn_i = blockIdx.x % tilesN;
+  // XCD-aware remap (bijective): hardware places block b on XCD b % 8; give each XCD a contiguous tile range
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm_i = bid / tilesN, tn_i = bid % tilesN;
   const int m0 = tm_i * BM, n0 = tn_i * BN;
   const int z1 = blockIdx.y / p.Z2, z2 = blockIdx.y % p.Z2;
 
@@ -77,8 +104,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     b_ok[i] = n < p.N;
     b_base[i] = B + (long)n * p.ldb;
   }
-  // running (tap, channel) of this thread's chunk column
-  int kc = kq * CH, tap = 0, cc = kc;
+  // K range of this block (split-K over blockIdx.z; steps of BK)
+  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
+  const int nk_all = nk1 + nk2;
+  int kt0 = 0, kt1 = nk_all;
+  if (p.splitk > 1) {
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    kt0 = blockIdx.z * per;
+    kt1 = min(nk_all, kt0 + per);
+  }
+  // running (k, tap, channel) of this thread's chunk column
+  int kl = kt0;                       // next step to load
+  int klim = p.K;
+  int kc = kt0 * BK + kq * CH, tap = 0, cc = kc;
   if (p.gather != GATHER_NONE) {
     tap = kc / p.Cin;
     cc = kc - tap * p.Cin;
@@ -86,7 +125,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   uint4 ra[NA], rb[NB];
   auto gload = [&]() {
-    const bool kok = kc < p.K;
+    if (nk2 && kl == nk1) {           // switch to the second operand pair
+      const T* A2 = (const T*)p.A2 + (long)(z1 / p.divA2) * p.sA21 + (long)z2 * p.sA22;
+      const T* B2 = (const T*)p.B2 + (long)(z1 / p.divB2) * p.sB21 + (long)z2 * p.sB22;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a_base[i] = A2 + (long)(m0 + ((tid + i * 256) >> 2)) * p.lda2;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) b_base[i] = B2 + (long)(n0 + ((tid + i * 256) >> 2)) * p.ldb2;
+      kc = kq * CH;
+      klim = p.K2;
+    }
+    ++kl;
+    const bool kok = kc < klim;
     int ky = 0, kx = 0;
     if (p.gather != GATHER_NONE && p.KS == 3) {
       ky = (tap * 11) >> 5;
@@ -172,14 +222,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   const int wy = wave >> 1, wx = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int nk = (p.K + BK - 1) / BK;
 
-  gload();
-  sstore(0);
+  if (kt0 < kt1) {
+    gload();
+    sstore(0);
+  }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) gload();
     const T* as = As + buf * A_ELEMS;
     const T* bs = Bs + buf * B_ELEMS;
     if constexpr (F32) {
@@ -211,33 +262,109 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) sstore(buf ^ 1);
+    if (kt + 1 < kt1) sstore(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue through LDS.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* stage = reinterpret_cast<float*>(smem_raw) + wave * 32 * SLD;
+  constexpr int CPR = WN / 8;                    // 8-column chunks per staged row
+  constexpr int ITEMS = 32 * CPR / 64;           // chunks per lane per 32-row slab
+  float* slab = p.splitk > 1 ? p.slab + ((long)blockIdx.z * gridDim.y + blockIdx.y) * (long)p.M * p.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wx * WN + j * 32 + l31;
-      if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wy * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m >= p.M) continue;
-        float v = p.alpha * acc[i][j][r] + bv;
-        if (p.rowbias) {
-          int smp = (m / p.rows_per_sample) / p.rowbias_div;
-          v += TT<T>::ld((const T*)p.rowbias + (long)smp * p.N + n);
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item / CPR, c8 = item % CPR;
+      const int m = m0 + wy * WM + i * 32 + row;
+      const int n = n0 + wx * WN + c8 * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      Vec<float>::load(stage + row * SLD + c8 * 8, v);
+      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
+      if (slab) {                                   // split-K partial: raw fp32, reduced by splitk_reduce_kernel
+        float* sp = slab + (long)m * p.N + n;
+        if (n + 8 <= p.N && !(p.N & 3)) {
+          Vec<float>::store(sp, v);
+          Vec<float>::store(sp + 4, v + 4);
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) sp[e] = v[e];
         }
-        if (R) v += TT<T>::ld(R + (long)m * p.ldr + n);
-        T* cp = C + (long)m * p.ldc + n;
-        if (p.accumulate) v += TT<T>::ld(cp);
-        TT<T>::st(cp, v);
+        continue;
+      }
+      const bool full = p.vec_ok && n + 8 <= p.N;
+      int smp = 0;
+      if (p.rowbias) smp = (m / p.rows_per_sample) / p.rowbias_div;
+      T* cp = C + (long)m * p.ldc + n;
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        if (p.bias) {
+          float b8[8];
+          V8<float>::load(p.bias + n, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (p.rowbias) {
+          float b8[8];
+          V8<T>::load((const T*)p.rowbias + (long)smp * p.N + n, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (R) {
+          float b8[8];
+          V8<T>::load(R + (long)m * p.ldr + n, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (p.accumulate) {
+          float b8[8];
+          V8<T>::load(cp, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        V8<T>::store(cp, v);
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float x = p.alpha * v[e];
+          if (p.bias) x += p.bias[n + e];
+          if (p.rowbias) x += TT<T>::ld((const T*)p.rowbias + (long)smp * p.N + n + e);
+          if (R) x += TT<T>::ld(R + (long)m * p.ldr + n + e);
+          if (p.accumulate) x += TT<T>::ld(cp + e);
+          TT<T>::st(cp + e, x);
+        }
       }
     }
+    __syncthreads();
+  }
+}
+
+// sums the split-K fp32 slabs and applies the fused epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
+  const long MN = (long)p.M * p.N;
+  const int Z = p.Z1 * p.Z2;
+  const long total = MN * Z;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int z = (int)(idx / MN);
+    const long mn = idx - (long)z * MN;
+    const int m = (int)(mn / p.N), n = (int)(mn - (long)m * p.N);
+    float acc = 0.f;
+    for (int s = 0; s < p.splitk; ++s) acc += p.slab[((long)s * Z + z) * MN + mn];
+    const int z1 = z / p.Z2, z2 = z % p.Z2;
+    float x = p.alpha * acc;
+    if (p.bias) x += p.bias[n];
+    if (p.rowbias) x += TT<T>::ld((const T*)p.rowbias + (long)((m / p.rows_per_sample) / p.rowbias_div) * p.N + n);
+    if (p.R) x += TT<T>::ld((const T*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 + (long)m * p.ldr + n);
+    T* cp = (T*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2 + (long)m * p.ldc + n;
+    if (p.accumulate) x += TT<T>::ld(cp);
+    TT<T>::st(cp, x);
   }
 }
 
@@ -246,28 +373,55 @@ int gemm_uses_big_tile(const GemmArgs& a) {
   return t128 >= 192 && a.N > 64;
 }
 
+// number of K splits for under-filled launches (0/1 = none)
+int gemm_pick_splitk(int dtype, const GemmArgs& a) {
+  if (gemm_uses_big_tile(a) || a.A2 || !a.slab) return 1;
+  const int BK = dtype == DT_F32 ? 16 : 32;
+  const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
+  const int nk = (a.K + BK - 1) / BK;
+  if (tiles >= 256 || nk < 32) return 1;
+  long s = (1024 + tiles - 1) / tiles;          // aim at ~4 blocks per CU
+  s = std::min<long>(s, nk / 8);                // keep >= 8 K steps per block
+  s = std::min<long>(s, 32);
+  const long need = s * (long)a.M * a.N * a.Z1 * a.Z2 * 4;
+  if (need > (long)a.slab_bytes) s = (long)a.slab_bytes / ((long)a.M * a.N * a.Z1 * a.Z2 * 4);
+  return (int)std::max<long>(s, 1);
+}
+
 template <typename T>
-static int launch_t(const GemmArgs& a, hipStream_t st) {
+static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
   if (a.K % CH || a.lda % CH || a.ldb % CH || (a.gather != GATHER_NONE && a.Cin % CH)) {
     set_error("gemm: K=%d lda=%d ldb=%d Cin=%d must be multiples of %d", a.K, a.lda, a.ldb, a.Cin, CH);
     return -1;
   }
+  if (a.A2 && (a.K2 % CH || a.lda2 % CH || a.ldb2 % CH || a.gather != GATHER_NONE)) {
+    set_error("gemm: second operand pair misaligned or combined with a gather");
+    return -1;
+  }
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K); return -1; }
+  a.vec_ok = !(a.ldc & 7) && !(a.sC1 & 7) && !(a.sC2 & 7) && (!a.R || (!(a.ldr & 7) && !(a.sR1 & 7) && !(a.sR2 & 7))) &&
+             (!a.rowbias || !(a.N & 7)) && !((uintptr_t)a.C & 15) && !((uintptr_t)a.R & 15) && !((uintptr_t)a.bias & 15);
   const int Z = a.Z1 * a.Z2;
+  a.splitk = gemm_pick_splitk(dtype, a);
   if (gemm_uses_big_tile(a)) {
-    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z);
+    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, 1);
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
   } else {
-    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), Z);
+    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), Z, a.splitk);
     hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, a);
+    if (a.splitk > 1) {
+      long total = (long)a.M * a.N * Z;
+      unsigned g = (unsigned)std::min<long>((total + 255) / 256, 4096);
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+    }
   }
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
-  return dtype == DT_F32 ? launch_t<float>(a, st) : launch_t<bf16>(a, st);
+  return dtype == DT_F32 ? launch_t<float>(dtype, a, st) : launch_t<bf16>(dtype, a, st);
 }
 
 }  // namespace dpb

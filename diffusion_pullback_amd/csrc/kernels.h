@@ -1,5 +1,7 @@
 // Host-side launch interface of the gfx950 kernels (internal; the public C-ABI is include/dpb.h).
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace dpb {
@@ -24,6 +26,13 @@ struct GemmArgs {
   // gather description (A is [samples][H*W][Cin] NHWC, output pixels Ho x Wo, KS x KS taps)
   int gather = GATHER_NONE;
   int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, KS = 1, stride = 1, pad = 0;
+  // optional second operand pair appended to the K loop (plain rows only)
+  const void* A2 = nullptr; const void* B2 = nullptr;
+  int K2 = 0, lda2 = 0, ldb2 = 0, divA2 = 1, divB2 = 1;
+  long sA21 = 0, sA22 = 0, sB21 = 0, sB22 = 0;
+  // split-K scratch (fp32 slabs); splitk / vec_ok are filled in by launch_gemm
+  float* slab = nullptr; size_t slab_bytes = 0;
+  int splitk = 1, vec_ok = 0;
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 int gemm_uses_big_tile(const GemmArgs& a);   // 1: 128x128 tile instantiation, 0: 64x64

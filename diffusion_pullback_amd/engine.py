@@ -162,6 +162,9 @@ class Engine:
     def profile(self, enable: bool):
         L.check(self.lib.dpb_engine_profile(self.h, int(enable)))
 
+    def profile_dump(self, path: str):
+        L.check(self.lib.dpb_engine_profile_dump(self.h, path.encode()))
+
     def profile_read(self, big_tile: bool):
         n = C.c_int64(); ms = C.c_double(); f = C.c_double()
         L.check(self.lib.dpb_engine_profile_read(self.h, int(big_tile), C.byref(n), C.byref(ms), C.byref(f)))
