@@ -1,0 +1,116 @@
+"""GPU tests of the DDIM / edit loop on the HIP engine (rows a9-a13 of the scope table): scheduler step vs the
+reference golden vectors, DDIM trajectories vs the CPU oracle, and the two drivers end to end on reduced nets."""
+import os
+
+import pytest
+import torch
+
+from _util import load_golden, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_scheduler_step_matches_reference_golden():
+    from diffusion_pullback_amd import scheduler as sch
+    f = load_golden("scheduler.pt")
+    s = sch.YHCustomScheduler()
+    xt, et = f["xt"].to(DEV), f["et"].to(DEV)
+    s.set_timesteps(100)
+    for i in (0, 30, 98):
+        r = s.step(et, s.timesteps[i], xt, eta=0.0)
+        torch.testing.assert_close(r.prev_sample.cpu(), f[f"step_fwd_{i}"], rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(r.x0.cpu(), f[f"x0_fwd_{i}"], rtol=2e-6, atol=2e-6)
+    s.set_timesteps(100, is_inversion=True)
+    for i in (0, 50, 97):
+        r = s.step(et, s.timesteps[i], xt, eta=0.0)
+        torch.testing.assert_close(r.prev_sample.cpu(), f[f"step_inv_{i}"], rtol=2e-6, atol=2e-6)
+
+
+def test_scheduler_step_eta_matches_oracle():
+    from diffusion_pullback_amd import scheduler as sch
+    from oracle import scheduler as osch
+    f = load_golden("scheduler.pt")
+    s = sch.YHCustomScheduler()
+    s.set_timesteps(100)
+    noise = torch.randn(f["xt"].shape, generator=torch.Generator().manual_seed(3))
+    ac, _ = osch.linear_alphas_cumprod()
+    ts, tn = osch.timesteps(100)
+    for i in (85, 97):
+        r = s.step(f["et"].to(DEV), s.timesteps[i], f["xt"].to(DEV), eta=1.0, noise=noise.to(DEV))
+        ref, x0 = osch.step(ac, ts, tn, f["et"], ts[i], f["xt"], eta=1.0, noise=noise)
+        torch.testing.assert_close(r.prev_sample.cpu(), ref, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(r.x0.cpu(), x0, rtol=1e-5, atol=1e-5)
+
+
+def _uncond_args(tmp, **kw):
+    from diffusion_pullback_amd import main as m
+    argv = ["--note", "t", "--model_name", "CelebA_HQ_HF", "--dataset_name", "CelebA_HQ", "--result_folder", str(tmp), "--device", DEV,
+            "--performance_boosting_t", "0.2", "--x_space_guidance_edit_step", "1", "--x_space_guidance_scale", "0.1",
+            "--x_space_guidance_num_step", "16", "--edit_t", "0.6", "--net_scale", "small", "--pca_rank", "3"]
+    a = m.preset(m.parse_args(argv))
+    a.input_root = os.path.join(str(tmp), "inputs")
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_uncond_ddim_trajectory_matches_oracle(tmp_path):
+    """inversion steps + forward steps on the engine vs the same loop with the CPU oracle U-Net / scheduler."""
+    from diffusion_pullback_amd import main as m
+    from diffusion_pullback_amd.edit import EditUncondDiffusion
+    from oracle import scheduler as osch
+    from oracle import unet_ddpm
+    a = _uncond_args(tmp_path)
+    unet = m.build_unet(a)
+    ed = EditUncondDiffusion(a, unet=unet)
+    cfg, p = unet.config, __import__("diffusion_pullback_amd.configs", fromlist=["x"]).ddpm_init_params(unet.config, seed=a.seed)
+    x = torch.randn(2, 3, cfg.resolution, cfg.resolution, generator=torch.Generator().manual_seed(5))
+    got, t, idx = ed.DDIMforwardsteps(x.to(DEV), t_start_idx=0, t_end_idx=6)
+    assert idx == 6 and float(t) == float(ed.scheduler.timesteps[6])
+    ac, _ = osch.linear_alphas_cumprod()
+    ts, tn = osch.timesteps(100)
+    ref = x
+    with torch.no_grad():
+        for i in range(6):
+            ref, _ = osch.step(ac, ts, tn, unet_ddpm.forward(p, cfg, ref, ts[i]), ts[i], ref)
+    assert rel(got, ref) < 1e-4, rel(got, ref)
+
+
+def test_uncond_driver_end_to_end(tmp_path):
+    from diffusion_pullback_amd import main as m
+    from diffusion_pullback_amd.edit import EditUncondDiffusion
+    a = _uncond_args(tmp_path)
+    ed = EditUncondDiffusion(a, unet=m.build_unet(a))
+    assert int(ed.edit_t_idx) == 40 and int(ed.performance_boosting_t_idx) == 80
+    xt = ed.run_edit_local_encoder_pullback_zt(idx=0, vis_num=4, vis_num_pc=1, pca_rank=3, op="mid", block_idx=0)
+    assert xt.shape[0] == 5                                                   # 17 latents subsampled [::4] (edit.py:301-302)
+    u, vT = ed.last_basis
+    assert u.shape[1] == 3 and vT.shape == (3, 3 * 32 * 32)
+    g = (vT @ vT.T).cpu()
+    assert torch.allclose(g, torch.eye(3), atol=1e-3)
+    d = os.path.join(a.input_root, "local_encoder_pullback_uncond-model_CelebA_HQ_HF-dataset_CelebA_HQ-num_steps_100-pca_rank_3")
+    name = "local_basis-CelebA_HQ_0-0.6T-mid-block_0-seed_0.pt"
+    assert os.path.exists(os.path.join(d, "u-" + name)) and os.path.exists(os.path.join(d, "vT-" + name))
+    outs = os.listdir(a.result_folder)
+    assert any(o.startswith("x0_gen-Edit_xt-CelebA_HQ_0-edit_0.6T-mid-block_0-pc_000_pos") for o in outs)
+    assert any(o.startswith("x0_gen-Edit_xt-CelebA_HQ_0-edit_0.6T-mid-block_0-pc_000_neg") for o in outs)
+    # second call hits the .pt cache and the "already done" skip
+    ed.run_edit_local_encoder_pullback_zt(idx=0, vis_num=4, vis_num_pc=1, pca_rank=3, op="mid", block_idx=0)
+
+
+def test_sd_driver_end_to_end(tmp_path):
+    from diffusion_pullback_amd import main as m
+    argv = ["--note", "t", "--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Examples", "--result_folder", str(tmp_path),
+            "--device", DEV, "--edit_prompt", "sitting dog", "--x_space_guidance_scale", "1", "--x_space_guidance_num_step", "8",
+            "--edit_t", "0.7", "--for_steps", "20", "--inv_steps", "20", "--net_scale", "small", "--pca_rank", "2", "--dtype", "bf16",
+            "--run_edit_local_encoder_pullback_zt", "False"]
+    a = m.preset(m.parse_args(argv))
+    a.input_root = os.path.join(str(tmp_path), "inputs")
+    from diffusion_pullback_amd.edit import EditStableDiffusion
+    ed = EditStableDiffusion(a, unet=m.build_unet(a))
+    res = ed.run_edit_local_encoder_pullback_zt(idx=5, op="mid", block_idx=0, vis_num=4, vis_num_pc=1, pca_rank=2, edit_prompt="tiger")
+    assert len(res) == 2 and res[0].shape == (5, 4, 16, 16)                  # 9 latents subsampled [::9 // 4] -> rows 0,2,4,6,8
+    d = os.path.join(a.input_root, "local_encoder_pullback_stable_diffusion-dataset_Examples-num_steps_20-pca_rank_2")
+    assert os.path.exists(os.path.join(d, 'vT-local_basis-Examples_5-0.7T-"tiger"-mid-block_0-seed_0.pt'))
+    assert torch.isfinite(res[0]).all()
