@@ -82,7 +82,7 @@ def test_uncond_driver_end_to_end(tmp_path):
     from diffusion_pullback_amd.edit import EditUncondDiffusion
     a = _uncond_args(tmp_path)
     ed = EditUncondDiffusion(a, unet=m.build_unet(a))
-    assert int(ed.edit_t_idx) == 40 and int(ed.performance_boosting_t_idx) == 80
+    assert int(ed.edit_t_idx) == 40 and int(ed.performance_boosting_t_idx) == 79   # |t - 200| minimal at 201.8
     xt = ed.run_edit_local_encoder_pullback_zt(idx=0, vis_num=4, vis_num_pc=1, pca_rank=3, op="mid", block_idx=0)
     assert xt.shape[0] == 5                                                   # 17 latents subsampled [::4] (edit.py:301-302)
     u, vT = ed.last_basis
