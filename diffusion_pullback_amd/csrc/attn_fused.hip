@@ -1,0 +1,462 @@
+// Fused (flash-style) tangent and adjoint self-attention for the long-sequence layers (bf16, head dim 40 / 80).
+//
+// The materialised path writes and re-reads k*heads*L^2 scores several times per pass (1.3 GB each at L = 4096,
+// k = 5); these kernels recompute the probabilities tile by tile from Q, K and the primal row statistics
+// (m_i = row max, l_i = row sum of exp, kept from the primal pass) and never touch HBM with an L x L object.
+//
+//   tangent :  dO_i = sum_j P_ij dS_ij V_j + sum_j P_ij dV_j - delta_i O_i ,  dS = scale (dQ K^T + Q dK^T),
+//              delta_i = sum_j P_ij dS_ij                                      [attn_jvp_kernel]
+//   adjoint :  gP_ij = gO_i . V_j ,  D_i = gO_i . O_i ,  gS = P o (gP - D)
+//              gQ_i = scale sum_j gS_ij K_j                                     [attn_adj_q_kernel, query-major]
+//              gK_j = scale sum_i gS_ij Q_i ,  gV_j = sum_i P_ij gO_i           [attn_adj_kv_kernel, key-major]
+//
+// Structure (all three): 4 waves per block, each wave owns 32 rows of the "outer" index (queries, or keys for the
+// kv kernel) held as MFMA B operands in registers; 64-row tiles of the "inner" index stream through LDS.  Score
+// products are computed transposed (inner index = MFMA row, outer = lane) so that each lane owns ONE outer row:
+// the softmax algebra is register-local and the probabilities re-enter the second MFMA as B fragments by a plain
+// fp32->bf16 pack, with no cross-lane movement.  The second-stage A operands come from the per-head transposed
+// copies ([d][L], key-contiguous) that the primal pass keeps (V^T, K^T, Q^T) or the caller provides (dV^T, gO^T).
+// v_mfma_f32_32x32x16_bf16 throughout; head dim padded to 48/80 for the score products and 64/96 for the outputs.
+#include "kernels.h"
+
+namespace dpb {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int D> struct FA {
+  static constexpr int NS = (D + 15) / 16;      // k-steps of the score products
+  static constexpr int DP = NS * 16;            // padded head dim (score products)
+  static constexpr int ND = (D + 31) / 32;      // 32-wide output tiles over the head dim
+  static constexpr int DO = ND * 32;
+  static constexpr int BI = 64;                 // inner rows per LDS stage
+  static constexpr int LDR = DP + 8;            // LDS stride of [row][d] tiles   (bf16 elements)
+  static constexpr int LDT = BI + 8;            // LDS stride of [d][row] tiles
+  static constexpr int ROW_ELEMS = BI * LDR;
+  static constexpr int T_ELEMS = DO * LDT;
+};
+
+// [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled
+template <int D>
+__device__ inline void load_row_tile(const bf16* __restrict__ src, long gs, bf16* lds, int tid) {
+  using F = FA<D>;
+  constexpr int CPR = F::DP / 8;
+  for (int c = tid; c < F::BI * CPR; c += 256) {
+    const int r = c / CPR, cc = (c % CPR) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (cc < D) v = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
+    *reinterpret_cast<uint4*>(lds + r * F::LDR + cc) = v;
+  }
+}
+// [D rows][BI cols] sub-matrix of a transposed copy (row stride gs) -> LDS [DO][LDT], rows D..DO zero filled
+template <int D>
+__device__ inline void load_t_tile(const bf16* __restrict__ src, long gs, bf16* lds, int tid) {
+  using F = FA<D>;
+  constexpr int CPR = F::BI / 8;
+  for (int c = tid; c < F::DO * CPR; c += 256) {
+    const int r = c / CPR, cc = (c % CPR) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < D) v = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
+    *reinterpret_cast<uint4*>(lds + r * F::LDT + cc) = v;
+  }
+}
+// B-operand fragments of 32 outer rows (row = lane&31), zero beyond D
+template <int D>
+__device__ inline void load_outer_frags(const bf16* __restrict__ rowptr, bf16x8* f, int lhi) {
+  using F = FA<D>;
+#pragma unroll
+  for (int st = 0; st < F::NS; ++st) {
+    const int col = st * 16 + lhi * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (col < D) v = *reinterpret_cast<const uint4*>(rowptr + col);
+    f[st] = *reinterpret_cast<bf16x8*>(&v);
+  }
+}
+__device__ inline bf16x8 lds_a_frag(const bf16* tile, int row, int ld, int col) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * ld + col);
+}
+// A fragment of a [d][row] tile for one 16-wide k-step: element j <-> inner row base + 4*lhi + (j&3) + 8*(j>>2)
+__device__ inline bf16x8 lds_t_frag(const bf16* tile, int drow, int ld, int base, int lhi) {
+  uint2 lo = *reinterpret_cast<const uint2*>(tile + drow * ld + base + 4 * lhi);
+  uint2 hi = *reinterpret_cast<const uint2*>(tile + drow * ld + base + 8 + 4 * lhi);
+  uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+__device__ inline void pack_b(const float* x, bf16x8* out) {   // 16 fp32 (acc register order) -> two B fragments
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(x[ks * 8 + 2 * i]) | ((unsigned)f2bf(x[ks * 8 + 2 * i + 1]) << 16);
+    uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+    out[ks] = *reinterpret_cast<bf16x8*>(&v);
+  }
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+struct FusedArgs {
+  const bf16 *Q, *K, *V, *O;          // primal [B][L][C]
+  const bf16 *KT, *VT, *QT;           // primal per-head transposes [B][H][d][L]
+  const float* stats;                 // primal row statistics [B][H][L][2] = (m, 1/l) of the scaled scores
+  const bf16 *dQ, *dK, *dV, *dVT;     // tangent inputs [nt][L][C], dV^T [nt][H][d][L]
+  bf16* dO;                           // tangent output [nt][L][C]
+  const bf16 *gO, *gOT;               // cotangent of the output [nt][L][C], gO^T [nt][H][d][L]
+  bf16 *gQ, *gK, *gV;                 // cotangent outputs [nt][L][C]
+  int accQ, accK, accV;               // accumulate into existing cotangents
+  int L, C, H, kps;
+  float scale;
+};
+
+// ------------------------------------------------------------------------------------------------ tangent
+template <int D>
+__global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
+  using F = FA<D>;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
+  bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sVT = sdK + F::ROW_ELEMS; bf16* sdVT = sVT + F::T_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const long LC = (long)a.L * a.C;
+  const bf16* Qp = a.Q + b * LC + h * D;
+  const bf16* Kp = a.K + b * LC + h * D;
+  const bf16* dQp = a.dQ + j * LC + h * D;
+  const bf16* dKp = a.dK + j * LC + h * D;
+  const bf16* VTp = a.VT + ((long)b * a.H + h) * D * a.L;
+  const bf16* dVTp = a.dVT + ((long)j * a.H + h) * D * a.L;
+  bf16x8 qf[F::NS], dqf[F::NS];
+  load_outer_frags<D>(Qp + (long)q * a.C, qf, lhi);
+  load_outer_frags<D>(dQp + (long)q * a.C, dqf, lhi);
+  const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
+  const float c2 = a.scale * 1.44269504088896f;
+  const float m2 = st[0] * 1.44269504088896f, il = st[1];
+  f32x16 acc[F::ND];
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float delta = 0.f;
+  for (int k0 = 0; k0 < a.L; k0 += F::BI) {
+    __syncthreads();
+    load_row_tile<D>(Kp + (long)k0 * a.C, a.C, sK, tid);
+    load_row_tile<D>(dKp + (long)k0 * a.C, a.C, sdK, tid);
+    load_t_tile<D>(VTp + k0, a.L, sVT, tid);
+    load_t_tile<D>(dVTp + k0, a.L, sdVT, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = ds[r] = 0.f;
+#pragma unroll
+      for (int stp = 0; stp < F::NS; ++stp) {
+        bf16x8 kf = lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
+        bf16x8 dkf = lds_a_frag(sdK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
+        s = MFMA(kf, qf[stp], s);
+        ds = MFMA(kf, dqf[stp], ds);
+        ds = MFMA(dkf, qf[stp], ds);
+      }
+      float p[16], x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = exp2f(c2 * s[r] - m2) * il;
+        x[r] = p[r] * (a.scale * ds[r]);
+        delta += x[r];
+      }
+      bf16x8 pb[2], xb[2];
+      pack_b(p, pb);
+      pack_b(x, xb);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int d = 0; d < F::ND; ++d) {
+          bf16x8 vf = lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+          bf16x8 dvf = lds_t_frag(sdVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+          acc[d] = MFMA(vf, xb[ks], acc[d]);
+          acc[d] = MFMA(dvf, pb[ks], acc[d]);
+        }
+    }
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  // dO[q][dcol] = acc - delta * O[q][dcol];  lane owns query q, register r <-> dcol = d*32 + (r&3) + 8*(r>>2) + 4*lhi
+  const bf16* Op = a.O + b * LC + (long)q * a.C + h * D;
+  bf16* dOp = a.dO + j * LC + (long)q * a.C + h * D;
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = d * 32 + 8 * g + 4 * lhi;
+      if (col < D) {
+        uint2 ov = *reinterpret_cast<const uint2*>(Op + col);
+        unsigned ow[2] = {ov.x, ov.y};
+        unsigned w[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float o0 = __uint_as_float(ow[i] << 16), o1 = __uint_as_float(ow[i] & 0xffff0000u);
+          float v0 = acc[d][g * 4 + 2 * i] - delta * o0, v1 = acc[d][g * 4 + 2 * i + 1] - delta * o1;
+          w[i] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+        }
+        *reinterpret_cast<uint2*>(dOp + col) = make_uint2(w[0], w[1]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ adjoint, query-major (gQ)
+template <int D>
+__global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
+  using F = FA<D>;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
+  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const long LC = (long)a.L * a.C;
+  const bf16* Kp = a.K + b * LC + h * D;
+  const bf16* Vp = a.V + b * LC + h * D;
+  const bf16* KTp = a.KT + ((long)b * a.H + h) * D * a.L;
+  bf16x8 qf[F::NS], gof[F::NS], of[F::NS];
+  load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
+  load_outer_frags<D>(a.gO + j * LC + (long)q * a.C + h * D, gof, lhi);
+  load_outer_frags<D>(a.O + b * LC + (long)q * a.C + h * D, of, lhi);
+  float Dq = 0.f;   // D_q = gO_q . O_q  (each lane holds half of the columns)
+#pragma unroll
+  for (int stp = 0; stp < F::NS; ++stp) {
+    const unsigned short* g16 = reinterpret_cast<const unsigned short*>(&gof[stp]);
+    const unsigned short* o16 = reinterpret_cast<const unsigned short*>(&of[stp]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Dq += bf2f(g16[e]) * bf2f(o16[e]);
+  }
+  Dq += __shfl_xor(Dq, 32, 64);
+  const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
+  const float c2 = a.scale * 1.44269504088896f;
+  const float m2 = st[0] * 1.44269504088896f, il = st[1];
+  f32x16 acc[F::ND];
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  for (int k0 = 0; k0 < a.L; k0 += F::BI) {
+    __syncthreads();
+    load_row_tile<D>(Kp + (long)k0 * a.C, a.C, sK, tid);
+    load_row_tile<D>(Vp + (long)k0 * a.C, a.C, sV, tid);
+    load_t_tile<D>(KTp + k0, a.L, sKT, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, gp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = gp[r] = 0.f;
+#pragma unroll
+      for (int stp = 0; stp < F::NS; ++stp) {
+        s = MFMA(lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), qf[stp], s);
+        gp = MFMA(lds_a_frag(sV, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), gof[stp], gp);
+      }
+      float gs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gs[r] = exp2f(c2 * s[r] - m2) * il * (gp[r] - Dq);
+      bf16x8 gsb[2];
+      pack_b(gs, gsb);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int d = 0; d < F::ND; ++d)
+          acc[d] = MFMA(lds_t_frag(sKT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi), gsb[ks], acc[d]);
+    }
+  }
+  bf16* gQp = a.gQ + j * LC + (long)q * a.C + h * D;
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = d * 32 + 8 * g + 4 * lhi;
+      if (col < D) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a.scale * acc[d][g * 4 + i];
+        if (a.accQ) {
+          uint2 ov = *reinterpret_cast<const uint2*>(gQp + col);
+          v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
+          v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2*>(gQp + col) =
+            make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
+template <int D>
+__global__ __launch_bounds__(256) void attn_adj_kv_kernel(FusedArgs a) {
+  using F = FA<D>;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
+  __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
+  bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS; bf16* sQT = sgO + F::ROW_ELEMS; bf16* sgOT = sQT + F::T_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
+  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  const long LC = (long)a.L * a.C;
+  const bf16* Qp = a.Q + b * LC + h * D;
+  const bf16* Op = a.O + b * LC + h * D;
+  const bf16* gOp = a.gO + j * LC + h * D;
+  const bf16* QTp = a.QT + ((long)b * a.H + h) * D * a.L;
+  const bf16* gOTp = a.gOT + ((long)j * a.H + h) * D * a.L;
+  const float* stp_ = a.stats + ((long)b * a.H + h) * a.L * 2;
+  bf16x8 kf[F::NS], vf[F::NS];
+  load_outer_frags<D>(a.K + b * LC + (long)key * a.C + h * D, kf, lhi);
+  load_outer_frags<D>(a.V + b * LC + (long)key * a.C + h * D, vf, lhi);
+  const float c2 = a.scale * 1.44269504088896f;
+  f32x16 accK[F::ND], accV[F::ND];
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
+  for (int q0 = 0; q0 < a.L; q0 += F::BI) {
+    __syncthreads();
+    load_row_tile<D>(Qp + (long)q0 * a.C, a.C, sQ, tid);
+    load_row_tile<D>(gOp + (long)q0 * a.C, a.C, sgO, tid);
+    load_t_tile<D>(QTp + q0, a.L, sQT, tid);
+    load_t_tile<D>(gOTp + q0, a.L, sgOT, tid);
+    if (tid < F::BI) {       // per-query statistics of this stage, D_q = gO_q . O_q
+      const int qq = q0 + tid;
+      sstat[0][tid] = stp_[2 * qq] * 1.44269504088896f;
+      sstat[1][tid] = stp_[2 * qq + 1];
+      float dq = 0.f;
+      for (int c = 0; c < D; c += 8) {
+        float g8[8], o8[8];
+        Vec<bf16>::load(gOp + (long)qq * a.C + c, g8);
+        Vec<bf16>::load(Op + (long)qq * a.C + c, o8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dq += g8[e] * o8[e];
+      }
+      sstat[2][tid] = dq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s, gp;     // [query = register row][key = lane]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = gp[r] = 0.f;
+#pragma unroll
+      for (int stp = 0; stp < F::NS; ++stp) {
+        s = MFMA(lds_a_frag(sQ, qb * 32 + l31, F::LDR, stp * 16 + lhi * 8), kf[stp], s);
+        gp = MFMA(lds_a_frag(sgO, qb * 32 + l31, F::LDR, stp * 16 + lhi * 8), vf[stp], gp);
+      }
+      float p[16], gs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        p[r] = exp2f(c2 * s[r] - sstat[0][qi]) * sstat[1][qi];
+        gs[r] = p[r] * (gp[r] - sstat[2][qi]);
+      }
+      bf16x8 pb[2], gsb[2];
+      pack_b(p, pb);
+      pack_b(gs, gsb);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int d = 0; d < F::ND; ++d) {
+          accV[d] = MFMA(lds_t_frag(sgOT, d * 32 + l31, F::LDT, qb * 32 + ks * 16, lhi), pb[ks], accV[d]);
+          accK[d] = MFMA(lds_t_frag(sQT, d * 32 + l31, F::LDT, qb * 32 + ks * 16, lhi), gsb[ks], accK[d]);
+        }
+    }
+  }
+  bf16* gKp = a.gK + j * LC + (long)key * a.C + h * D;
+  bf16* gVp = a.gV + j * LC + (long)key * a.C + h * D;
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = d * 32 + 8 * g + 4 * lhi;
+      if (col < D) {
+        float vk[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { vk[i] = a.scale * accK[d][g * 4 + i]; vv[i] = accV[d][g * 4 + i]; }
+        if (a.accK) {
+          uint2 ov = *reinterpret_cast<const uint2*>(gKp + col);
+          vk[0] += __uint_as_float(ov.x << 16); vk[1] += __uint_as_float(ov.x & 0xffff0000u);
+          vk[2] += __uint_as_float(ov.y << 16); vk[3] += __uint_as_float(ov.y & 0xffff0000u);
+        }
+        if (a.accV) {
+          uint2 ov = *reinterpret_cast<const uint2*>(gVp + col);
+          vv[0] += __uint_as_float(ov.x << 16); vv[1] += __uint_as_float(ov.x & 0xffff0000u);
+          vv[2] += __uint_as_float(ov.y << 16); vv[3] += __uint_as_float(ov.y & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2*>(gKp + col) =
+            make_uint2((unsigned)f2bf(vk[0]) | ((unsigned)f2bf(vk[1]) << 16), (unsigned)f2bf(vk[2]) | ((unsigned)f2bf(vk[3]) << 16));
+        *reinterpret_cast<uint2*>(gVp + col) =
+            make_uint2((unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16), (unsigned)f2bf(vv[2]) | ((unsigned)f2bf(vv[3]) << 16));
+      }
+    }
+}
+
+// row statistics of the primal probabilities from the materialised scaled scores S (before softmax):
+// one wave per row; stats[row] = (max, 1 / sum exp(S - max))
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* stats, long nrows, int Lk, int ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const bf16* sp = S + row * ld;
+  float m = -INFINITY;
+  for (int c = lane * 8; c < Lk; c += 512) {
+    float v[8];
+    Vec<bf16>::load(sp + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (c + e < Lk) m = fmaxf(m, v[e]);
+  }
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane * 8; c < Lk; c += 512) {
+    float v[8];
+    Vec<bf16>::load(sp + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (c + e < Lk) s += __expf(v[e] - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) { stats[2 * row] = m; stats[2 * row + 1] = 1.f / s; }
+}
+
+int fused_attention_supported(int dtype, int d, int L, int kv_const) {
+  return dtype == DT_BF16 && !kv_const && (d == 40 || d == 80) && L >= 1024 && L % 128 == 0;
+}
+
+int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st) {
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, (const bf16*)S, stats, nrows, Lk, ld);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+static FusedArgs to_args(const FusedAttnArgs& f) {
+  FusedArgs a;
+  a.Q = (const bf16*)f.Q; a.K = (const bf16*)f.K; a.V = (const bf16*)f.V; a.O = (const bf16*)f.O;
+  a.KT = (const bf16*)f.KT; a.VT = (const bf16*)f.VT; a.QT = (const bf16*)f.QT; a.stats = f.stats;
+  a.dQ = (const bf16*)f.dQ; a.dK = (const bf16*)f.dK; a.dV = (const bf16*)f.dV; a.dVT = (const bf16*)f.dVT; a.dO = (bf16*)f.dO;
+  a.gO = (const bf16*)f.gO; a.gOT = (const bf16*)f.gOT; a.gQ = (bf16*)f.gQ; a.gK = (bf16*)f.gK; a.gV = (bf16*)f.gV;
+  a.accQ = f.accQ; a.accK = f.accK; a.accV = f.accV;
+  a.L = f.L; a.C = f.C; a.H = f.H; a.kps = f.kps; a.scale = f.scale;
+  return a;
+}
+
+int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
+  FusedArgs a = to_args(f);
+  dim3 grid(f.L / 128, nt * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_jvp_kernel<40>), grid, dim3(256), 0, st, a);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_jvp_kernel<80>), grid, dim3(256), 0, st, a);
+  else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
+  FusedArgs a = to_args(f);
+  dim3 grid(f.L / 128, nt * f.H);
+  if (f.d == 40) {
+    hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(256), 0, st, a);
+  } else if (f.d == 80) {
+    hipLaunchKernelGGL((attn_adj_q_kernel<80>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<80>), grid, dim3(256), 0, st, a);
+  } else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dpb

@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -45,8 +46,8 @@ struct Buf {
 
 struct AttnPlan {            // per attention op, persisted from the primal pass
   int heads = 0, d = 0, Lq = 0, Lk = 0, Lqp = 0, Lkp = 0;
-  bool kv_const = false;
-  size_t P = 0, PT = 0, KT = 0, VT = 0, QT = 0;   // offsets
+  bool kv_const = false, fused = false;
+  size_t P = 0, PT = 0, KT = 0, VT = 0, QT = 0, stats = 0;   // offsets
 };
 
 struct Op {
@@ -341,6 +342,10 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
   g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = B; g.Z2 = H; g.alpha = scale;
   if (int r = gemm(e, g)) return r;
   e->n_launch += 3;
+  if (p.fused) {
+    e->n_launch++;
+    if (int r = launch_row_stats(ws + p.P, (float*)(ws + p.stats), (long)B * H * p.Lq, p.Lk, p.Lkp, e->stream)) return r;
+  }
   if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
   // V^T, K^T per head ([d][Lkp], zero padded)
   if (int r = launch_transpose(e->dtype, e->P(d.in2), ws + p.VT, B, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
@@ -366,6 +371,18 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
   const float scale = 1.f / sqrtf((float)p.d);
   char* ws = e->ws;
   char* S1 = ws + e->S1;
+  if (p.fused) {
+    char* T1 = ws + e->T1;
+    e->n_launch += 2;
+    if (int r = launch_transpose(e->dtype, e->T(d.in2), T1, nt, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    FusedAttnArgs f;
+    f.Q = e->P(d.in0); f.K = e->P(d.in1); f.V = e->P(d.in2); f.O = e->P(d.out); f.VT = ws + p.VT; f.KT = ws + p.KT; f.QT = ws + p.QT;
+    f.stats = (const float*)(ws + p.stats);
+    f.dQ = e->T(d.in0); f.dK = e->T(d.in1); f.dV = e->T(d.in2); f.dVT = T1; f.dO = e->T(d.out);
+    f.L = p.Lq; f.C = C; f.H = H; f.d = p.d; f.kps = kps; f.scale = scale;
+    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 5 * nt * H;
+    return launch_attn_jvp_fused(f, nt, e->stream);
+  }
   GemmArgs g;   // dS = scale * dQ K^T
   g.A = e->T(d.in0); g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
   g.B = e->P(d.in1); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
@@ -404,6 +421,21 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   char* S1 = ws + e->S1;
   float* Dv = (float*)(ws + e->Dv);
   const char* gO = e->G(d.out);
+  if (p.fused) {
+    char* T1 = ws + e->T1;
+    e->n_launch += 3;
+    if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * C, p.d, p.Lq, p.d, C, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+    FusedAttnArgs f;
+    f.Q = e->P(d.in0); f.K = e->P(d.in1); f.V = e->P(d.in2); f.O = e->P(d.out); f.VT = ws + p.VT; f.KT = ws + p.KT; f.QT = ws + p.QT;
+    f.stats = (const float*)(ws + p.stats);
+    f.gO = gO; f.gOT = T1; f.gQ = e->G(d.in0); f.gK = e->G(d.in1); f.gV = e->G(d.in2);
+    f.accQ = e->ginit[d.in0]; f.accK = e->ginit[d.in1]; f.accV = e->ginit[d.in2];
+    f.L = p.Lq; f.C = C; f.H = H; f.d = p.d; f.kps = kps; f.scale = scale;
+    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;
+    if (int r = launch_attn_adj_fused(f, nt, e->stream)) return r;
+    e->ginit[d.in0] = e->ginit[d.in1] = e->ginit[d.in2] = 1;
+    return 0;
+  }
   GemmArgs g;   // gP = gO V^T
   g.A = gO; g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
   g.B = e->P(d.in2); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
@@ -575,6 +607,8 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       s1 = std::max(s1, (size_t)e->maxT * H * p.Lq * p.Lkp * es);
       size_t lmax = std::max(p.Lqp, p.Lkp);
       t1 = std::max(t1, (size_t)e->maxT * H * p.d * lmax * es);
+      p.fused = fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN");
+      if (p.fused) p.stats = take((size_t)e->maxB * H * p.Lq * 2 * sizeof(float));
       if (!p.kv_const) {
         p.PT = take((size_t)e->maxB * H * p.Lk * p.Lqp * es);
         p.QT = take((size_t)e->maxB * H * p.d * p.Lqp * es);

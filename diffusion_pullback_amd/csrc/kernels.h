@@ -75,6 +75,21 @@ int launch_softmax_adjT(int dtype, const void* PT, void* gPT, const float* D, lo
 int launch_transpose(int dtype, const void* in, void* out, int Z1, int Z2, long s1, long s2, int R, int Ccols, int ldin,
                      int ldout, long outZstride, hipStream_t st);
 
+// fused (flash-style) tangent / adjoint self-attention, bf16, head dim 40 or 80 (attn_fused.hip)
+struct FusedAttnArgs {
+  const void *Q = nullptr, *K = nullptr, *V = nullptr, *O = nullptr, *KT = nullptr, *VT = nullptr, *QT = nullptr;
+  const float* stats = nullptr;
+  const void *dQ = nullptr, *dK = nullptr, *dV = nullptr, *dVT = nullptr; void* dO = nullptr;
+  const void *gO = nullptr, *gOT = nullptr; void *gQ = nullptr, *gK = nullptr, *gV = nullptr;
+  int accQ = 0, accK = 0, accV = 0;
+  int L = 0, C = 0, H = 0, d = 0, kps = 1;
+  float scale = 1.f;
+};
+int fused_attention_supported(int dtype, int d, int L, int kv_const);
+int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st);
+int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st);
+int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st);
+
 // ---------------------------------------------------------------- elementwise
 struct GegluArgs {
   const void* h = nullptr;     // primal [Bp*rows][2F]
