@@ -161,15 +161,15 @@ def main():
         eng.iterate(tap, V0_d.clone(), 1)
         if os.environ.get("DPB_PROFILE_CSV"):
             eng.profile_dump(os.environ["DPB_PROFILE_CSV"])
-        n_big, ms_big, fl_big = eng.profile_read(True)
-        n_small, ms_small, fl_small = eng.profile_read(False)
+        n_big, ms_big, fl_big = eng.profile_read(False)      # dominant instantiation: the 64x64 tile (see gemm.hip)
+        n_small, ms_small, fl_small = eng.profile_read(True)
         eng.profile(False)
         ach = fl_big / (ms_big * 1e-3) / 1e12 if ms_big > 0 else 0.0
         mac = MAC_G.get(a.workload)
-        res["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dname},128,128>", "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s",
+        res["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dname},64,64>", "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s",
                            "frac": ach / PEAK[dname], "traffic": None,
                            "launches_per_iter": n_big, "avg_launch_us": 1e3 * ms_big / max(n_big, 1), "flops_per_iter": fl_big,
-                           "small_tile": {"kernel": f"gemm_kernel<{dname},64,64>", "launches_per_iter": n_small, "avg_launch_us": 1e3 * ms_small / max(n_small, 1),
+                           "other_tile": {"kernel": f"gemm_kernel<{dname},128,128>", "launches_per_iter": n_small, "avg_launch_us": 1e3 * ms_small / max(n_small, 1),
                                           "achieved": fl_small / (ms_small * 1e-3) / 1e12 if ms_small > 0 else 0.0},
                            "gemm_time_share_of_step": (ms_big + ms_small) / res["ms_per_step"],
                            "algorithmic_flops_per_step": 2 * k * 2 * mac * 1e9 if mac else None,

@@ -832,6 +832,16 @@ int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double*
   return 0;
 }
 
+int dpb_debug_set(const char* key, int value) {
+  static int tile = 0, splitk = 0;
+  if (!key) return fail("null key");
+  if (!strcmp(key, "gemm_tile")) tile = value;
+  else if (!strcmp(key, "gemm_splitk")) splitk = value;
+  else return fail("unknown debug key %s", key);
+  gemm_debug_set(tile, splitk);
+  return 0;
+}
+
 int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes) {
   if (!e) return fail("null engine");
   if (launches) *launches = e->n_launch;

@@ -368,23 +368,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
   }
 }
 
+// tuning overrides (dpb_debug_set): 0 = heuristic
+static int g_force_tile = 0, g_force_splitk = 0;
+void gemm_debug_set(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
+
 int gemm_uses_big_tile(const GemmArgs& a) {
-  long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
-  return t128 >= 192 && a.N > 64;
+  // Measured on MI355X (tests/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt): with this single-stage register
+  // prefetch the 64x64 tile (7 blocks/CU in flight) beats the 128x128 tile (latency-bound at <= 4 blocks/CU) on every
+  // layer shape of the path, so the big tile is only selectable explicitly until it gets a deeper pipeline.
+  (void)a;
+  return g_force_tile == 128;
 }
 
-// number of K splits for under-filled launches (0/1 = none)
+// number of K splits for under-filled launches (1 = none)
 int gemm_pick_splitk(int dtype, const GemmArgs& a) {
-  if (gemm_uses_big_tile(a) || a.A2 || !a.slab) return 1;
+  if (a.A2 || !a.slab) return 1;
   const int BK = dtype == DT_F32 ? 16 : 32;
-  const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
+  const int T = gemm_uses_big_tile(a) ? 128 : 64;
+  const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + BK - 1) / BK;
-  if (tiles >= 256 || nk < 32) return 1;
-  long s = (1024 + tiles - 1) / tiles;          // aim at ~4 blocks per CU
-  s = std::min<long>(s, nk / 8);                // keep >= 8 K steps per block
-  s = std::min<long>(s, 32);
-  const long need = s * (long)a.M * a.N * a.Z1 * a.Z2 * 4;
-  if (need > (long)a.slab_bytes) s = (long)a.slab_bytes / ((long)a.M * a.N * a.Z1 * a.Z2 * 4);
+  long s;
+  if (g_force_splitk) {
+    s = g_force_splitk;
+  } else {
+    if (T == 128 || tiles >= 768 || nk < 32) return 1;
+    s = (1024 + tiles - 1) / tiles;             // aim at ~4 blocks per CU
+    s = std::min<long>(s, nk / 8);              // keep >= 8 K steps per block
+    s = std::min<long>(s, 32);
+  }
+  s = std::min<long>(s, nk);
+  const long per = (long)a.M * a.N * a.Z1 * a.Z2 * 4;
+  if (s * per > (long)a.slab_bytes) s = (long)a.slab_bytes / per;
   return (int)std::max<long>(s, 1);
 }
 
@@ -405,16 +419,16 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   const int Z = a.Z1 * a.Z2;
   a.splitk = gemm_pick_splitk(dtype, a);
   if (gemm_uses_big_tile(a)) {
-    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, 1);
+    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
   } else {
     dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), Z, a.splitk);
     hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, a);
-    if (a.splitk > 1) {
-      long total = (long)a.M * a.N * Z;
-      unsigned g = (unsigned)std::min<long>((total + 255) / 256, 4096);
-      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
-    }
+  }
+  if (a.splitk > 1) {
+    long total = (long)a.M * a.N * Z;
+    unsigned g = (unsigned)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
   }
   DPB_CHECK(hipGetLastError());
   return 0;

@@ -134,7 +134,8 @@ int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops,
  * (big_tile=0) instantiation: count, total milliseconds, algorithmic flops. */
 int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double* total_ms, double* flops);
-int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);   /* one line per recorded GEMM launch */
+int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
+int dpb_debug_set(const char* key, int value);   /* tuning overrides for micro-benchmarks: "gemm_tile" (0|64|128), "gemm_splitk" (0|n) */   /* one line per recorded GEMM launch */
 
 #ifdef __cplusplus
 }
