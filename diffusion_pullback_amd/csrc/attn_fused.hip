@@ -36,28 +36,54 @@ template <int D> struct FA {
   static constexpr int T_ELEMS = DO * LDT;
 };
 
-// [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled
+// Register-staged tile loads: fetch() issues the global loads of the NEXT stage before the MFMAs of the current one,
+// commit() writes them to LDS after the barrier, so HBM/L2 latency overlaps the compute.
+// Row tile: [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled.
+template <int D> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + 255) / 256]; };
 template <int D>
-__device__ inline void load_row_tile(const bf16* __restrict__ src, long gs, bf16* lds, int tid) {
+__device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<D>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8;
-  for (int c = tid; c < F::BI * CPR; c += 256) {
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * 256;
     const int r = c / CPR, cc = (c % CPR) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (cc < D) v = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
-    *reinterpret_cast<uint4*>(lds + r * F::LDR + cc) = v;
+    rg.v[i] = make_uint4(0, 0, 0, 0);
+    if (c < F::BI * CPR && cc < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
   }
 }
-// [D rows][BI cols] sub-matrix of a transposed copy (row stride gs) -> LDS [DO][LDT], rows D..DO zero filled
 template <int D>
-__device__ inline void load_t_tile(const bf16* __restrict__ src, long gs, bf16* lds, int tid) {
+__device__ inline void commit_row(const RowRegs<D>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8;
-  for (int c = tid; c < F::DO * CPR; c += 256) {
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * 256;
+    if (c < F::BI * CPR) *reinterpret_cast<uint4*>(lds + (c / CPR) * F::LDR + (c % CPR) * 8) = rg.v[i];
+  }
+}
+// T tile: [D rows][BI cols] sub-matrix of a transposed copy (row stride gs) -> LDS [DO][LDT], rows D..DO zero filled.
+template <int D> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + 255) / 256]; };
+template <int D>
+__device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D>& rg, int tid) {
+  using F = FA<D>;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * 256;
     const int r = c / CPR, cc = (c % CPR) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < D) v = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
-    *reinterpret_cast<uint4*>(lds + r * F::LDT + cc) = v;
+    rg.v[i] = make_uint4(0, 0, 0, 0);
+    if (c < F::DO * CPR && r < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
+  }
+}
+template <int D>
+__device__ inline void commit_t(const TRegs<D>& rg, bf16* lds, int tid) {
+  using F = FA<D>;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * 256;
+    if (c < F::DO * CPR) *reinterpret_cast<uint4*>(lds + (c / CPR) * F::LDT + (c % CPR) * 8) = rg.v[i];
   }
 }
 // B-operand fragments of 32 outer rows (row = lane&31), zero beyond D
@@ -84,13 +110,9 @@ __device__ inline bf16x8 lds_t_frag(const bf16* tile, int drow, int ld, int base
 }
 __device__ inline void pack_b(const float* x, bf16x8* out) {   // 16 fp32 (acc register order) -> two B fragments
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    unsigned w[4];
+  for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(x[ks * 8 + 2 * i]) | ((unsigned)f2bf(x[ks * 8 + 2 * i + 1]) << 16);
-    uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-    out[ks] = *reinterpret_cast<bf16x8*>(&v);
-  }
+    for (int i = 0; i < 8; ++i) out[ks][i] = (__bf16)x[ks * 8 + i];       // v_cvt_pk_bf16_f32
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
@@ -135,13 +157,19 @@ __global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float delta = 0.f;
+  RowRegs<D> rK, rdK;
+  TRegs<D> rVT, rdVT;
+  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(dKp, a.C, rdK, tid);
+  fetch_t<D>(VTp, a.L, rVT, tid); fetch_t<D>(dVTp, a.L, rdVT, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
+    __syncthreads();                      // previous stage fully consumed
+    commit_row<D>(rK, sK, tid); commit_row<D>(rdK, sdK, tid); commit_t<D>(rVT, sVT, tid); commit_t<D>(rdVT, sdVT, tid);
     __syncthreads();
-    load_row_tile<D>(Kp + (long)k0 * a.C, a.C, sK, tid);
-    load_row_tile<D>(dKp + (long)k0 * a.C, a.C, sdK, tid);
-    load_t_tile<D>(VTp + k0, a.L, sVT, tid);
-    load_t_tile<D>(dVTp + k0, a.L, sdVT, tid);
-    __syncthreads();
+    if (k0 + F::BI < a.L) {               // prefetch the next stage under this stage's MFMAs
+      const int k1 = k0 + F::BI;
+      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(dKp + (long)k1 * a.C, a.C, rdK, tid);
+      fetch_t<D>(VTp + k1, a.L, rVT, tid); fetch_t<D>(dVTp + k1, a.L, rdVT, tid);
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, ds;
@@ -234,12 +262,17 @@ __global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
   for (int d = 0; d < F::ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  RowRegs<D> rK, rV;
+  TRegs<D> rKT;
+  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(Vp, a.C, rV, tid); fetch_t<D>(KTp, a.L, rKT, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();
-    load_row_tile<D>(Kp + (long)k0 * a.C, a.C, sK, tid);
-    load_row_tile<D>(Vp + (long)k0 * a.C, a.C, sV, tid);
-    load_t_tile<D>(KTp + k0, a.L, sKT, tid);
+    commit_row<D>(rK, sK, tid); commit_row<D>(rV, sV, tid); commit_t<D>(rKT, sKT, tid);
     __syncthreads();
+    if (k0 + F::BI < a.L) {
+      const int k1 = k0 + F::BI;
+      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_t<D>(KTp + k1, a.L, rKT, tid);
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, gp;
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
 template <int D>
-__global__ __launch_bounds__(256) void attn_adj_kv_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
   __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
@@ -309,16 +342,14 @@ __global__ __launch_bounds__(256) void attn_adj_kv_kernel(FusedArgs a) {
   for (int d = 0; d < F::ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
-  for (int q0 = 0; q0 < a.L; q0 += F::BI) {
-    __syncthreads();
-    load_row_tile<D>(Qp + (long)q0 * a.C, a.C, sQ, tid);
-    load_row_tile<D>(gOp + (long)q0 * a.C, a.C, sgO, tid);
-    load_t_tile<D>(QTp + q0, a.L, sQT, tid);
-    load_t_tile<D>(gOTp + q0, a.L, sgOT, tid);
-    if (tid < F::BI) {       // per-query statistics of this stage, D_q = gO_q . O_q
+  RowRegs<D> rQ, rgO;
+  TRegs<D> rQT, rgOT;
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+  auto fetch_stats = [&](int q0) {       // per-query statistics of a stage, D_q = gO_q . O_q
+    if (tid < F::BI) {
       const int qq = q0 + tid;
-      sstat[0][tid] = stp_[2 * qq] * 1.44269504088896f;
-      sstat[1][tid] = stp_[2 * qq + 1];
+      st0 = stp_[2 * qq] * 1.44269504088896f;
+      st1 = stp_[2 * qq + 1];
       float dq = 0.f;
       for (int c = 0; c < D; c += 8) {
         float g8[8], o8[8];
@@ -327,9 +358,22 @@ __global__ __launch_bounds__(256) void attn_adj_kv_kernel(FusedArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq += g8[e] * o8[e];
       }
-      sstat[2][tid] = dq;
+      st2 = dq;
     }
+  };
+  fetch_row<D>(Qp, a.C, rQ, tid); fetch_row<D>(gOp, a.C, rgO, tid); fetch_t<D>(QTp, a.L, rQT, tid); fetch_t<D>(gOTp, a.L, rgOT, tid);
+  fetch_stats(0);
+  for (int q0 = 0; q0 < a.L; q0 += F::BI) {
     __syncthreads();
+    commit_row<D>(rQ, sQ, tid); commit_row<D>(rgO, sgO, tid); commit_t<D>(rQT, sQT, tid); commit_t<D>(rgOT, sgOT, tid);
+    if (tid < F::BI) { sstat[0][tid] = st0; sstat[1][tid] = st1; sstat[2][tid] = st2; }
+    __syncthreads();
+    if (q0 + F::BI < a.L) {
+      const int q1 = q0 + F::BI;
+      fetch_row<D>(Qp + (long)q1 * a.C, a.C, rQ, tid); fetch_row<D>(gOp + (long)q1 * a.C, a.C, rgO, tid);
+      fetch_t<D>(QTp + q1, a.L, rQT, tid); fetch_t<D>(gOTp + q1, a.L, rgOT, tid);
+      fetch_stats(q1);
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s, gp;     // [query = register row][key = lane]

@@ -17,12 +17,17 @@ __host__ __device__ inline float bf2f(unsigned short v) {
   return c.f;
 }
 __host__ __device__ inline unsigned short f2bf(float f) {   // round to nearest even
+#if defined(__HIP_DEVICE_COMPILE__)
+  __bf16 b = (__bf16)f;                   // v_cvt_pk_bf16_f32 on gfx950
+  return *reinterpret_cast<unsigned short*>(&b);
+#else
   union { unsigned u; float f; } c;
   c.f = f;
   unsigned u = c.u;
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+#endif
 }
 
 template <typename T> struct TT;
@@ -61,10 +66,11 @@ template <> struct Vec<bf16> {
     }
   }
   __device__ static inline void store(bf16* p, const float* o) {
-    unsigned w[4];
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    v8 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)o[i];          // 4 x v_cvt_pk_bf16_f32
+    *reinterpret_cast<v8*>(p) = r;
   }
 };
 

@@ -833,12 +833,13 @@ int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double*
 }
 
 int dpb_debug_set(const char* key, int value) {
-  static int tile = 0, splitk = 0;
+  static int tile = 0, splitk = 0, kch = 0;
   if (!key) return fail("null key");
   if (!strcmp(key, "gemm_tile")) tile = value;
   else if (!strcmp(key, "gemm_splitk")) splitk = value;
+  else if (!strcmp(key, "gemm_kch")) kch = value;
   else return fail("unknown debug key %s", key);
-  gemm_debug_set(tile, splitk);
+  gemm_debug_set(tile, splitk, kch);
   return 0;
 }
 

@@ -39,16 +39,17 @@ template <> struct V8<bf16> {
   __device__ static inline void store(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
 };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int KCH>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int CH = TT<T>::CH;
-  constexpr int BK = 4 * CH;
+  constexpr int BK = KCH * CH;           // K elements per step (KCH 16-byte chunks per row)
+  constexpr int RPP = 256 / KCH;          // tile rows covered by one pass of the 256 threads
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int LDA_S = F32 ? (BM + 4) : (BK + 8);
   constexpr int LDB_S = F32 ? (BN + 4) : (BK + 8);
   constexpr int A_ELEMS = F32 ? BK * LDA_S : BM * LDA_S;
   constexpr int B_ELEMS = F32 ? BK * LDB_S : BN * LDB_S;
-  constexpr int NA = BM / 64, NB = BN / 64;
+  constexpr int NA = BM / RPP, NB = BN / RPP;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int SLD = WN + 4;                                   // stage row stride (floats)
   constexpr int MAIN_BYTES = 2 * (A_ELEMS + B_ELEMS) * (int)sizeof(T);
@@ -75,14 +76,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   T* C = (T*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2;
   const T* R = p.R ? (const T*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 : nullptr;
 
-  const int kq = tid & 3;
+  const int kq = tid % KCH, r0 = tid / KCH;
   // ---- per-thread A rows
   const T* a_base[NA];
   int a_oy[NA], a_ox[NA];
   bool a_ok[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    int row = (tid + i * 256) >> 2;
+    int row = r0 + i * RPP;
     int m = m0 + row;
     a_ok[i] = m < p.M;
     a_oy[i] = a_ox[i] = 0;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   bool b_ok[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    int n = n0 + ((tid + i * 256) >> 2);
+    int n = n0 + r0 + i * RPP;
     b_ok[i] = n < p.N;
     b_base[i] = B + (long)n * p.ldb;
   }
@@ -129,9 +130,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       const T* A2 = (const T*)p.A2 + (long)(z1 / p.divA2) * p.sA21 + (long)z2 * p.sA22;
       const T* B2 = (const T*)p.B2 + (long)(z1 / p.divB2) * p.sB21 + (long)z2 * p.sB22;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) a_base[i] = A2 + (long)(m0 + ((tid + i * 256) >> 2)) * p.lda2;
+      for (int i = 0; i < NA; ++i) a_base[i] = A2 + (long)(m0 + r0 + i * RPP) * p.lda2;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) b_base[i] = B2 + (long)(n0 + ((tid + i * 256) >> 2)) * p.ldb2;
+      for (int i = 0; i < NB; ++i) b_base[i] = B2 + (long)(n0 + r0 + i * RPP) * p.ldb2;
       kc = kq * CH;
       klim = p.K2;
     }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     T* bs = Bs + buf * B_ELEMS;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int row = (tid + i * 256) >> 2;
+      int row = r0 + i * RPP;
       if constexpr (F32) {
         const float* f = reinterpret_cast<const float*>(&ra[i]);
 #pragma unroll
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      int row = (tid + i * 256) >> 2;
+      int row = r0 + i * RPP;
       if constexpr (F32) {
         const float* f = reinterpret_cast<const float*>(&rb[i]);
 #pragma unroll
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < BK / 16; ++kk) {
         bf16x8 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
 }
 
 // tuning overrides (dpb_debug_set): 0 = heuristic
-static int g_force_tile = 0, g_force_splitk = 0;
-void gemm_debug_set(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
+static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0;
+void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
 
 int gemm_uses_big_tile(const GemmArgs& a) {
   // Measured on MI355X (tests/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt): with this single-stage register
@@ -380,10 +381,15 @@ int gemm_uses_big_tile(const GemmArgs& a) {
   return g_force_tile == 128;
 }
 
+int gemm_kch(const GemmArgs& a) {
+  if (g_kch) return g_kch;
+  return 4;
+}
+
 // number of K splits for under-filled launches (1 = none)
 int gemm_pick_splitk(int dtype, const GemmArgs& a) {
   if (a.A2 || !a.slab) return 1;
-  const int BK = dtype == DT_F32 ? 16 : 32;
+  const int BK = (dtype == DT_F32 ? 4 : 8) * gemm_kch(a);
   const int T = gemm_uses_big_tile(a) ? 128 : 64;
   const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + BK - 1) / BK;
@@ -420,10 +426,11 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   a.splitk = gemm_pick_splitk(dtype, a);
   if (gemm_uses_big_tile(a)) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 4>), grid, dim3(256), 0, st, a);
   } else {
     dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), Z, a.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, a);
+    if (gemm_kch(a) == 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 4>), grid, dim3(256), 0, st, a);
   }
   if (a.splitk > 1) {
     long total = (long)a.M * a.N * Z;

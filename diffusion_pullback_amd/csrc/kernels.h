@@ -36,7 +36,8 @@ struct GemmArgs {
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 int gemm_uses_big_tile(const GemmArgs& a);
-void gemm_debug_set(int tile, int splitk);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
+void gemm_debug_set(int tile, int splitk, int kch);
+int gemm_kch(const GemmArgs& a);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
 
 // ---------------------------------------------------------------- normalisation
 enum { MODE_PRIMAL = 0, MODE_TANGENT = 1, MODE_ADJOINT = 2 };

@@ -21,13 +21,13 @@ def conv_engine(H, cin, cout, ks, dtype, batch):
     return Engine(t, 8, False, True, cin, max_batch=batch, max_tangents=batch)
 
 
-def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((0, 0), (64, 0), (128, 0), (64, 4), (128, 2), (128, 4))):
+def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((64, 0, 4), (64, 0, 8), (64, 2, 4), (64, 2, 8), (64, 4, 8))):
     e = conv_engine(H, cin, cout, ks, dtype, batch)
     x = torch.randn(batch, cin, H, H, device=DEV)
     M, N, K = batch * H * H, cout, ks * ks * cin
     out = []
-    for tile, sk in variants:
-        L.check(lib.dpb_debug_set(b"gemm_tile", tile)); L.check(lib.dpb_debug_set(b"gemm_splitk", sk))
+    for tile, sk, kch in variants:
+        L.check(lib.dpb_debug_set(b"gemm_tile", tile)); L.check(lib.dpb_debug_set(b"gemm_splitk", sk)); L.check(lib.dpb_debug_set(b"gemm_kch", kch))
         for _ in range(3):
             e.primal(x, 1.0, None, "o")
         e.profile(True)
@@ -36,8 +36,8 @@ def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((0, 0), (
         nb, msb, fb = e.profile_read(True); ns, mss, fs = e.profile_read(False)
         e.profile(False)
         ms = (msb + mss) / 10
-        out.append(f"t{tile}/s{sk}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:6.0f}TF")
-    L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
+        out.append(f"t{tile}/s{sk}/k{kch}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:6.0f}TF")
+    L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0)); L.check(lib.dpb_debug_set(b"gemm_kch", 0))
     print(f"{name:28s} M={M:6d} N={N:5d} K={K:6d} | " + " | ".join(out), flush=True)
 
 
@@ -51,5 +51,5 @@ if __name__ == "__main__":
     run("lin 16^2 1280->1280 b5", 16, 1280, 1280, 1, 5)
     run("lin 64^2 320->2560 b5", 64, 320, 2560, 1, 5)
     run("lin 32^2 640->5120 b5", 32, 640, 5120, 1, 5)
-    run("conv3x3 256^2 128->128 f32 b5", 256, 128, 128, 3, 5, torch.float32, ((0, 0), (64, 0)))
-    run("conv3x3 64^2 256->256 f32 b5", 64, 256, 256, 3, 5, torch.float32, ((0, 0), (64, 0), (128, 2)))
+    run("conv3x3 256^2 128->128 f32 b5", 256, 128, 128, 3, 5, torch.float32, ((64, 0, 4), (64, 0, 8)))
+    run("conv3x3 64^2 256->256 f32 b5", 64, 256, 256, 3, 5, torch.float32, ((64, 0, 4), (64, 0, 8), (64, 2, 8)))
