@@ -40,13 +40,15 @@ def parse():
     ap.add_argument("--workload", default="sd15", choices=["sd15", "ddpm256", "toy"])
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--samples-per-gpu", type=int, default=1,
+                    help="x_t samples advanced together per GPU (independent bases, shared weight stream); steps must be a multiple")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-k", type=int, default=1, help="directions in the bounded CPU sample (scaled to k; 0 = all k)")
     return ap.parse_args()
 
 
-def make_workload(name, dtype, device, k, seed_base):
+def make_workload(name, dtype, device, k, spg):
     """-> (net, get_h_oracle, samples x [S,...], t, ctx, V0[k,N], tap)"""
     from diffusion_pullback_amd import PullbackUNet
     g = torch.Generator().manual_seed(0)
@@ -56,7 +58,7 @@ def make_workload(name, dtype, device, k, seed_base):
                                                                   up_attn=(False, True), heads=(2, 2), cross_dim=64, sample_size=16, ctx_len=77)
         enc = ("time_embedding", "conv_in", "down_blocks", "mid_block")
         params = cf.sd_init_params(cfg, seed=0, only_prefix=enc)
-        net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=1, max_rank=k, upto=("mid", 0), verbose=False)
+        net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=("mid", 0), verbose=False)
         t = 696.2727
         ctx = torch.randn(1, cfg.ctx_len, cfg.cross_dim, generator=g)          # fixed seeded "null" embedding
         shape = (cfg.in_channels, cfg.sample_size, cfg.sample_size)
@@ -67,7 +69,7 @@ def make_workload(name, dtype, device, k, seed_base):
         from diffusion_pullback_amd import configs as cf
         cfg = cf.CELEBA_HQ_256
         params = cf.ddpm_init_params(cfg, seed=0)
-        net = PullbackUNet("ddpm", cfg, params, dtype=dtype, device=device, max_batch=1, max_rank=k, upto=("mid", 0), verbose=False)
+        net = PullbackUNet("ddpm", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=("mid", 0), verbose=False)
         t, ctx = 600.0, None
         shape = (cfg.in_channels, cfg.resolution, cfg.resolution)
         def oracle_get_h(xb):      # cpu_baseline leg only
@@ -94,28 +96,32 @@ def main():
     dname = a.dtype or ("fp32" if a.workload == "ddpm256" else "bf16")
     dtype = torch.float32 if dname == "fp32" else torch.bfloat16
     k = a.k
-    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, rank)
+    S = a.samples_per_gpu
+    assert a.steps % S == 0 and a.warmup % S == 0, "--steps and --warmup must be multiples of --samples-per-gpu"
+    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, S)
     tap = ("mid", 0)
     eng = net.engine
 
-    n_samples = (a.steps + ITERS_PER_SAMPLE - 1) // ITERS_PER_SAMPLE
-    n_warm = (a.warmup + ITERS_PER_SAMPLE - 1) // ITERS_PER_SAMPLE if a.warmup > 0 else 0
+    group = S * ITERS_PER_SAMPLE                      # steps per group of S concurrently advanced samples
+    n_groups = (a.steps + group - 1) // group
+    n_warm = (a.warmup + group - 1) // group if a.warmup > 0 else 0
+    n_samples = n_groups * S
     gx = torch.Generator().manual_seed(1000 + rank)
-    xs = torch.randn(max(n_samples, n_warm, 1), *shape, generator=gx).to(dev)     # synthetic latents, resident in HBM
-    ctx_d = ctx.to(dev) if ctx is not None else None
-    V0_d = V0.to(dev)
+    xs = torch.randn(max(n_groups, n_warm, 1) * S, *shape, generator=gx).to(dev)   # synthetic latents, resident in HBM
+    ctx_d = ctx.to(dev).expand(S, -1, -1).contiguous() if ctx is not None else None
+    V0_d = V0.to(dev).repeat(S, 1).contiguous()           # same seeded V0 for every sample
 
     def run(steps, xs_):
         out = None
         done = 0
-        si = 0
+        gi = 0
         while done < steps:
-            n = min(ITERS_PER_SAMPLE, steps - done)
-            eng.primal(xs_[si:si + 1], t, ctx_d, tap)
+            n = min(ITERS_PER_SAMPLE, (steps - done) // S)
+            eng.primal(xs_[gi * S:(gi + 1) * S], t, ctx_d, tap)
             V = V0_d.clone()
             out = eng.iterate(tap, V, n)
-            done += n
-            si += 1
+            done += n * S
+            gi += 1
         return out
 
     if a.warmup > 0:
@@ -149,29 +155,30 @@ def main():
         "config": {"workload": {"sd15": "BASELINE configs[2]: SD-v1.5 4x64x64 latent, no edit prompt (seeded null ctx[1,77,768]), mid-block h[1280,8,8], t=696.27",
                                 "ddpm256": "BASELINE configs[1]: CelebA-HQ DDPM 256x256 x[3,256,256], mid-block h[512,8,8], t=600",
                                 "toy": "toy SD-style net (plumbing check)"}[a.workload],
-                   "pca_rank": k, "iters_per_sample": ITERS_PER_SAMPLE, "samples_per_gpu": n_samples,
+                   "pca_rank": k, "iters_per_sample": ITERS_PER_SAMPLE, "samples_timed_per_gpu": n_samples, "samples_advanced_together": S,
                    "parallelism": f"{world} x independent samples, final all_gather of (u,s,vT)" if world > 1 else "single GPU"},
-        "finite": finite, "s_top": [round(v, 5) for v in s.cpu().tolist()],
+        "finite": finite, "s_top": [round(v, 5) for v in s.cpu().tolist()[:k]],
     }
 
     if rank == 0 and not a.no_roofline:
         # ---- roofline leg: one instrumented iteration, HIP events around every GEMM launch on the engine stream
-        eng.primal(xs[0:1], t, ctx_d, tap)
+        eng.primal(xs[0:S], t, ctx_d, tap)
         eng.profile(True)
         eng.iterate(tap, V0_d.clone(), 1)
         if os.environ.get("DPB_PROFILE_CSV"):
             eng.profile_dump(os.environ["DPB_PROFILE_CSV"])
-        n_big, ms_big, fl_big = eng.profile_read(False)      # dominant instantiation: the 64x64 tile (see gemm.hip)
-        n_small, ms_small, fl_small = eng.profile_read(True)
+        kinds = {"gemm_kernel<%s,64,64,4>" % dname: eng.profile_read(0), "gemm_dma_kernel<4> (bf16 128x128 LDS ring)": eng.profile_read(2)}
         eng.profile(False)
-        ach = fl_big / (ms_big * 1e-3) / 1e12 if ms_big > 0 else 0.0
+        dom = max(kinds, key=lambda n: kinds[n][1])                      # dominant = most GPU time
+        n_d, ms_d, fl_d = kinds[dom]
+        ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
         mac = MAC_G.get(a.workload)
-        res["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dname},64,64>", "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s",
-                           "frac": ach / PEAK[dname], "traffic": None,
-                           "launches_per_iter": n_big, "avg_launch_us": 1e3 * ms_big / max(n_big, 1), "flops_per_iter": fl_big,
-                           "other_tile": {"kernel": f"gemm_kernel<{dname},128,128>", "launches_per_iter": n_small, "avg_launch_us": 1e3 * ms_small / max(n_small, 1),
-                                          "achieved": fl_small / (ms_small * 1e-3) / 1e12 if ms_small > 0 else 0.0},
-                           "gemm_time_share_of_step": (ms_big + ms_small) / res["ms_per_step"],
+        gemm_ms = sum(v[1] for v in kinds.values())
+        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach / PEAK[dname],
+                           "traffic": None, "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
+                           "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * v[1] / max(v[0], 1),
+                                                    "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},
+                           "gemm_time_share_of_step": gemm_ms / (res["ms_per_step"] * S),
                            "algorithmic_flops_per_step": 2 * k * 2 * mac * 1e9 if mac else None,
                            "whole_step_frac_of_peak": (2 * k * 2 * mac * 1e9 / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK[dname]) if mac else None}
 

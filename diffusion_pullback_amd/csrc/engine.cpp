@@ -74,7 +74,7 @@ struct dpb_engine {
   size_t ws_bytes = 0;
   // arena offsets
   size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0;
-  size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20;
+  size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20, zeros = 0;
   size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
   size_t temb_host_stage = 0;
   int cur_batch = 0;
@@ -104,6 +104,7 @@ int fail(const char* fmt, ...) {
 int gemm(dpb_engine* e, GemmArgs a) {
   e->n_launch++;
   a.slab = (float*)(e->ws + e->slab);
+  a.zeros = e->ws + e->zeros;
   a.slab_bytes = e->slab_bytes;
   const double kk = (double)a.K + (a.A2 ? a.K2 : 0);
   e->flops += 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
@@ -111,7 +112,7 @@ int gemm(dpb_engine* e, GemmArgs a) {
   if (!e->profiling) return launch_gemm(e->dtype, a, e->stream);
   dpb_engine::Prof p;
   p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
-  p.big = gemm_uses_big_tile(a);
+  p.big = gemm_uses_dma(e->dtype, a) ? 2 : gemm_uses_big_tile(a);
   p.M = a.M; p.N = a.N; p.K = a.K; p.Z = a.Z1 * a.Z2; p.gather = a.gather;
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));
@@ -635,8 +636,9 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   const size_t nio = (size_t)std::max(e->maxB, e->maxT) * maxrc * sizeof(float);
   e->io_in = take(nio);
   e->io_out = take(nio);
-  e->orth = take(sizeof(double) * (3 * 16 * 16 + 2));
+  e->orth = take(sizeof(double) * (3 * 16 * 16 + 2) * (size_t)e->maxB);
   e->slab = take(e->slab_bytes);
+  e->zeros = take(256);
   const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
   e->pbV = 0; e->pbW = take((size_t)e->maxT * nx * sizeof(float)); e->pbVn = take((size_t)e->maxT * nx * sizeof(float));
   e->ws_bytes = off;
@@ -765,21 +767,24 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
 
 int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, float* conv, int k, int n_iters) {
   if (!e || !V || !U || !s || !conv) return fail("null argument");
-  if (e->cur_batch != 1) return fail("dpb_pullback_iterate handles a single sample (batch 1); got batch %d", e->cur_batch);
   if (k < 1 || k > 16) return fail("pca_rank k=%d outside [1,16]", k);
-  if (int r = check_tap(e, tap, k)) return r;
+  const int B = e->cur_batch;                       // samples advanced together: one weight stream for all of them
+  if (int r = check_tap(e, tap, k * (B > 0 ? B : 1))) return r;
+  const int nt = k * B;
   const long N = (long)e->bufs[e->x_buf].rows * e->x_channels;
   float* Wm = (float*)(e->ws + e->pbW);
   float* Vn = (float*)(e->ws + e->pbVn);
   long launches = 0; double fl = 0, gb = 0;
   for (int it = 0; it < n_iters; ++it) {
-    if (int r = dpb_jvp(e, tap, V, k, U)) return r;
+    if (int r = dpb_jvp(e, tap, V, nt, U)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
-    if (int r = dpb_vjp(e, tap, U, k, Wm)) return r;
+    if (int r = dpb_vjp(e, tap, U, nt, Wm)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
-    if (int r = dpb_orth(Wm, V, Vn, s, conv, e->ws + e->orth, k, N, e->stream)) return r;
-    DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * k * N, hipMemcpyDeviceToDevice, e->stream));
-    launches += 6;
+    for (int b = 0; b < B; ++b)                     // independent k x N re-orthonormalisation per sample
+      if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, Vn + (long)b * k * N, s + b * k, conv + 2 * b,
+                           e->ws + e->orth + (size_t)b * sizeof(double) * (3 * 16 * 16 + 2), k, N, e->stream)) return r;
+    DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * nt * N, hipMemcpyDeviceToDevice, e->stream));
+    launches += 5 * B + 1;
   }
   e->n_launch = launches; e->flops = fl; e->gbytes = gb;
   return 0;
@@ -838,6 +843,7 @@ int dpb_debug_set(const char* key, int value) {
   if (!strcmp(key, "gemm_tile")) tile = value;
   else if (!strcmp(key, "gemm_splitk")) splitk = value;
   else if (!strcmp(key, "gemm_kch")) kch = value;
+  else if (!strcmp(key, "gemm_dma_auto")) { gemm_debug_dma_auto(value); return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

@@ -370,8 +370,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
 }
 
 // tuning overrides (dpb_debug_set): 0 = heuristic
-static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0;
+static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0, g_dma_auto = 1;
 void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
+void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 
 int gemm_uses_big_tile(const GemmArgs& a) {
   // Measured on MI355X (tests/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt): with this single-stage register
@@ -379,6 +380,15 @@ int gemm_uses_big_tile(const GemmArgs& a) {
   // layer shape of the path, so the big tile is only selectable explicitly until it gets a deeper pipeline.
   (void)a;
   return g_force_tile == 128;
+}
+
+// the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
+int gemm_uses_dma(int dtype, const GemmArgs& a) {
+  if (dtype != DT_BF16 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
+  if (g_force_tile == 129) return 1;
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
+  // measured (profiles/r01_gemm_microbench.txt): the ring wins once every CU holds >= ~2 tiles, loses when under-filled
+  return g_dma_auto && t128 >= 400 && a.K >= 256;
 }
 
 int gemm_kch(const GemmArgs& a) {
@@ -423,6 +433,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   a.vec_ok = !(a.ldc & 7) && !(a.sC1 & 7) && !(a.sC2 & 7) && (!a.R || (!(a.ldr & 7) && !(a.sR1 & 7) && !(a.sR2 & 7))) &&
              (!a.rowbias || !(a.N & 7)) && !((uintptr_t)a.C & 15) && !((uintptr_t)a.R & 15) && !((uintptr_t)a.bias & 15);
   const int Z = a.Z1 * a.Z2;
+  if (gemm_uses_dma(dtype, a)) { a.splitk = 1; return launch_gemm_dma(a, st); }
   a.splitk = gemm_pick_splitk(dtype, a);
   if (gemm_uses_big_tile(a)) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);

@@ -1,0 +1,258 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution with an asynchronous global->LDS ring (gfx950 LDS-DMA).
+//
+// Same contract as gemm_kernel (gemm.hip) for the single-operand-pair case, 128x128 tile, 4 waves (64x64 each).
+// What differs is how operands reach LDS: every wave issues `global_load_lds_dwordx4` (1 KiB per wave instruction,
+// no VGPR round trip, no ds_write pass) into a ring of S stages and keeps P = S-1 K-steps in flight; a stage is
+// consumed after a COUNTED `s_waitcnt vmcnt(4*(stages still in flight))` + one raw `s_barrier` per K-step.  The
+// register-staged kernel has exactly one K-step in flight per block and is latency-bound (measured 135-270 TF/s on
+// the path's shapes); this one hides the L2/HBM latency inside the block.
+//
+// LDS image of a stage: A tile [128 rows][4 x 16 B] then B tile [128][4 x 16 B], rows 64 B apart, NO padding (the DMA
+// writes lane-linear: wave-uniform base + lane*16).  Bank conflicts of the ds_read_b128 fragment reads are removed
+// by an XOR swizzle applied on the SOURCE side: LDS chunk (row, c) holds logical K-chunk c ^ ((row >> 2) & 3), and the
+// fragment reads apply the same involution.  Out-of-range rows / taps / K tails read a 16-byte zero page instead of
+// branching, so every wave issues exactly 4 DMA instructions per stage and the vmcnt arithmetic is static.
+// LDS fragment reads are inline asm (`ds_read_b128` + `s_waitcnt lgkmcnt(0)` + sched_barrier): hipcc would otherwise
+// put `s_waitcnt vmcnt(0)` in front of every compiler-visible LDS read while a DMA is pending and drain the ring.
+#include "kernels.h"
+
+namespace dpb {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ inline bf16x8 lds_read_b128(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
+  constexpr int BM = 128, BN = 128, BK = 32, CH = 8;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;     // 8 KiB + 8 KiB
+  constexpr int P = S - 1;                                             // K-steps in flight
+  constexpr int WM = 64, WN = 64, TM = 2, TN = 2, SLD = WN + 4;
+  __shared__ __attribute__((aligned(16))) char smem[S * STAGE];
+  static_assert(S * STAGE >= 4 * 32 * SLD * 4, "epilogue staging must fit in the ring");
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tilesN = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / tilesN) * BM, n0 = (bid % tilesN) * BN;
+  const int z1 = blockIdx.y / p.Z2, z2 = blockIdx.y % p.Z2;
+  const bf16* A = (const bf16*)p.A + (long)(z1 / p.divA) * p.sA1 + (long)z2 * p.sA2;
+  const bf16* B = (const bf16*)p.B + (long)(z1 / p.divB) * p.sB1 + (long)z2 * p.sB2;
+  bf16* C = (bf16*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2;
+  const bf16* R = p.R ? (const bf16*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 : nullptr;
+  const bf16* zero = (const bf16*)p.zeros;
+
+  // ---- DMA slots of this lane: wave instruction i covers LDS chunks (wave*2+i)*64 + lane of the A (B) tile
+  const bf16* a_base[2];
+  const bf16* b_base[2];
+  int a_oy[2], a_ox[2], kc[2], tap[2], cc[2];
+  bool a_ok[2], b_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pos = (wave * 2 + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
+    const int kq = phys ^ ((row >> 2) & 3);
+    kc[i] = kq * CH;
+    const int m = m0 + row, n = n0 + row;
+    a_ok[i] = m < p.M;
+    b_ok[i] = n < p.N;
+    b_base[i] = B + (long)n * p.ldb;
+    a_oy[i] = a_ox[i] = 0;
+    tap[i] = 0;
+    cc[i] = kc[i];
+    if (p.gather == GATHER_NONE) {
+      a_base[i] = A + (long)m * p.lda;
+    } else {
+      const int hw = p.Ho * p.Wo, smp = m / hw, rem = m - smp * hw;
+      a_oy[i] = rem / p.Wo;
+      a_ox[i] = rem - a_oy[i] * p.Wo;
+      a_base[i] = A + (long)smp * p.H * p.W * p.lda;
+      tap[i] = kc[i] / p.Cin;
+      cc[i] = kc[i] - tap[i] * p.Cin;
+    }
+  }
+  auto issue = [&](int slot) {
+    char* st = smem + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16* src = zero;
+      bool ok = a_ok[i] && kc[i] < p.K;
+      if (p.gather == GATHER_NONE) {
+        if (ok) src = a_base[i] + kc[i];
+      } else {
+        int ky = 0, kx = 0;
+        if (p.KS == 3) { ky = (tap[i] * 11) >> 5; kx = tap[i] - ky * 3; }
+        int iy, ix;
+        if (p.gather == GATHER_CONV) {
+          iy = a_oy[i] * p.stride + ky - p.pad;
+          ix = a_ox[i] * p.stride + kx - p.pad;
+          ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        } else if (p.gather == GATHER_CONVT) {
+          int ty = a_oy[i] + p.pad - ky, tx = a_ox[i] + p.pad - kx;
+          ok = ok && ty >= 0 && tx >= 0;
+          if (p.stride == 2) { ok = ok && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; } else { iy = ty; ix = tx; }
+          ok = ok && iy < p.H && ix < p.W;
+        } else {
+          int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
+          ok = ok && uy >= 0 && ux >= 0 && uy < 2 * p.H && ux < 2 * p.W;
+          iy = uy >> 1; ix = ux >> 1;
+        }
+        if (ok) src = a_base[i] + ((long)iy * p.W + ix) * p.lda + cc[i];
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16* src = (b_ok[i] && kc[i] < p.K) ? b_base[i] + kc[i] : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      kc[i] += BK;
+      if (p.gather != GATHER_NONE) {
+        cc[i] += BK;
+        while (cc[i] >= p.Cin) { cc[i] -= p.Cin; ++tap[i]; }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wy = wave >> 1, wx = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  // fragment read addresses (bytes, inside a stage): row*64 + ((kk*2+lhi) ^ ((row>>2)&3))*16
+  unsigned fa[TM][2], fb[TN][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wy * WM + i * 32 + l31, sw = (row >> 2) & 3;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fa[i][kk] = row * 64 + (((kk * 2 + lhi) ^ sw) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wx * WN + j * 32 + l31, sw = (row >> 2) & 3;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fb[j][kk] = A_BYTES + row * 64 + (((kk * 2 + lhi) ^ sw) << 4);
+  }
+
+  const int nk = (p.K + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < P; ++s)
+    if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt landed for this wave: everything issued after it may still be in flight (4 DMA instructions per stage)
+    const int later = min(P - 1, nk - 1 - kt);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // ... and for every other wave; also: stage kt-1 is fully consumed
+    if (kt + P < nk) issue((kt + P) % S);  // refill the slot stage kt-1 occupied
+    const unsigned sb = lds0 + (kt % S) * STAGE;
+    bf16x8 a[TM][2], b[TN][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i][kk] = lds_read_b128(sb + fa[i][kk]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j][kk] = lds_read_b128(sb + fb[j][kk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue through LDS (same scheme as gemm_kernel)
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+  constexpr int CPR = WN / 8, ITEMS = 32 * CPR / 64;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item / CPR, c8 = item % CPR;
+      const int m = m0 + wy * WM + i * 32 + row;
+      const int n = n0 + wx * WN + c8 * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      Vec<float>::load(stage + row * SLD + c8 * 8, v);
+      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
+      int smp = 0;
+      if (p.rowbias) smp = (m / p.rows_per_sample) / p.rowbias_div;
+      bf16* cp = C + (long)m * p.ldc + n;
+      if (p.vec_ok && n + 8 <= p.N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        float b8[8];
+        if (p.bias) {
+          Vec<float>::load(p.bias + n, b8);
+          Vec<float>::load(p.bias + n + 4, b8 + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (p.rowbias) {
+          Vec<bf16>::load((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (R) {
+          Vec<bf16>::load(R + (long)m * p.ldr + n, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (p.accumulate) {
+          Vec<bf16>::load(cp, b8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        Vec<bf16>::store(cp, v);
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float x = p.alpha * v[e];
+          if (p.bias) x += p.bias[n + e];
+          if (p.rowbias) x += TT<bf16>::ld((const bf16*)p.rowbias + (long)smp * p.N + n + e);
+          if (R) x += TT<bf16>::ld(R + (long)m * p.ldr + n + e);
+          if (p.accumulate) x += TT<bf16>::ld(cp + e);
+          TT<bf16>::st(cp + e, x);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
+  dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, 1);
+  hipLaunchKernelGGL((gemm_dma_kernel<4>), grid, dim3(256), 0, st, a);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dpb

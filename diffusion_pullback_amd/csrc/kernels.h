@@ -32,12 +32,16 @@ struct GemmArgs {
   long sA21 = 0, sA22 = 0, sB21 = 0, sB22 = 0;
   // split-K scratch (fp32 slabs); splitk / vec_ok are filled in by launch_gemm
   float* slab = nullptr; size_t slab_bytes = 0;
+  const void* zeros = nullptr;        // >= 16 zero bytes in device memory (DMA kernel reads it for padding / out-of-range rows)
   int splitk = 1, vec_ok = 0;
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 int gemm_uses_big_tile(const GemmArgs& a);
 void gemm_debug_set(int tile, int splitk, int kch);
-int gemm_kch(const GemmArgs& a);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
+int gemm_kch(const GemmArgs& a);
+int launch_gemm_dma(const GemmArgs& a, hipStream_t st);   // bf16, single operand pair, no split-K (gemm_dma.hip)
+int gemm_uses_dma(int dtype, const GemmArgs& a);
+void gemm_debug_dma_auto(int on);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
 
 // ---------------------------------------------------------------- normalisation
 enum { MODE_PRIMAL = 0, MODE_TANGENT = 1, MODE_ADJOINT = 2 };

@@ -147,15 +147,17 @@ class Engine:
         return V, s, conv
 
     def iterate(self, tap, V: torch.Tensor, n_iters: int):
-        """n_iters power iterations in place on V [k, N_in]; returns (V, U, s, conv) device tensors, no host sync."""
+        """n_iters power iterations in place on V [B*k, N_in] (B = batch of the last primal, independent bases);
+        returns (V, U [B*k, N_h], s [B*k], conv [B, 2]) device tensors, no host sync."""
         buf = self.tape.taps[tap]
         with torch.cuda.device(self.device):
             self._set_stream()
-            assert V.is_cuda and V.dtype == torch.float32 and V.is_contiguous()
-            k = V.shape[0]
-            U = torch.empty(k, self.tap_numel(tap), dtype=torch.float32, device=self.device)
-            s = torch.empty(k, dtype=torch.float32, device=self.device)
-            conv = torch.empty(2, dtype=torch.float32, device=self.device)
+            assert V.is_cuda and V.dtype == torch.float32 and V.is_contiguous() and V.shape[0] % self.batch == 0
+            nt = V.shape[0]
+            k = nt // self.batch
+            U = torch.empty(nt, self.tap_numel(tap), dtype=torch.float32, device=self.device)
+            s = torch.empty(nt, dtype=torch.float32, device=self.device)
+            conv = torch.empty(self.batch, 2, dtype=torch.float32, device=self.device)
             L.check(self.lib.dpb_pullback_iterate(self.h, buf, _ptr(V), _ptr(U), _ptr(s), _ptr(conv), k, n_iters))
         return V, U, s, conv
 
@@ -165,7 +167,7 @@ class Engine:
     def profile_dump(self, path: str):
         L.check(self.lib.dpb_engine_profile_dump(self.h, path.encode()))
 
-    def profile_read(self, big_tile: bool):
+    def profile_read(self, big_tile: int):
         n = C.c_int64(); ms = C.c_double(); f = C.c_double()
         L.check(self.lib.dpb_engine_profile_read(self.h, int(big_tile), C.byref(n), C.byref(ms), C.byref(f)))
         return n.value, ms.value, f.value

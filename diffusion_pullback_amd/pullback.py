@@ -140,8 +140,11 @@ class PullbackUNet:
         """Fixed-iteration variant with no host synchronisation (what bench.py times)."""
         key = self._tap(op, block_idx)
         self.engine.primal(x, _t_float(t), ctx, key)
-        V = V0.reshape(pca_rank, -1).to(device=self.device, dtype=torch.float32).contiguous().clone()
-        V, U, s, conv = self.engine.iterate(key, V, n_iters)
+        b = x.shape[0]                                  # b samples advance together; V0 is [b*k, N] or [k, N] (shared)
+        V = V0.reshape(-1, self.engine.n_in).to(device=self.device, dtype=torch.float32)
+        if V.shape[0] == pca_rank and b > 1:
+            V = V.repeat(b, 1)
+        V, U, s, conv = self.engine.iterate(key, V.contiguous().clone(), n_iters)
         return U.T, s, V, conv
 
 

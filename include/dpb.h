@@ -116,9 +116,10 @@ int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
              void* hip_stream);
 
-/* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev.
- * V [k][N_in] in/out, U [k][N_h] out, s [k] out, conv [2] out (of the last iteration).
- * Replaces: the loop body utils.py:756-808 (k <= 16, single sample). */
+/* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev, for all B samples
+ * of the last dpb_primal together (independent bases, one shared weight stream; B*k <= max_tangents).
+ * V [B][k][N_in] in/out, U [B][k][N_h] out, s [B][k] out, conv [B][2] out (of the last iteration).
+ * Replaces: the loop body utils.py:756-808 (k <= 16), once per sample of the batch. */
 int dpb_pullback_iterate(dpb_engine* e, int tap_buf, float* V, float* U, float* s, float* conv, int k, int n_iters);
 
 /* DDIM update (utils.py:301-306 / :1220-1225, eta = 0) and the x-space-guidance axpy (edit.py:490, :501). */
