@@ -385,10 +385,19 @@ int gemm_uses_big_tile(const GemmArgs& a) {
 // the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
 int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (dtype != DT_BF16 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
-  if (g_force_tile == 129) return 1;
+  if (g_force_tile == 129) return 128;
+  if (g_force_tile == 65) return 64;
+  if (g_force_tile == 67) return 66;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
-  // measured (profiles/r01_gemm_microbench.txt): the ring wins once every CU holds >= ~2 tiles, loses when under-filled
-  return g_dma_auto && t128 >= 400 && a.K >= 256;
+  const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
+  // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
+  // >= ~2 tiles; below that the 64x64 ring wins if it still fills the chip; long-K under-filled problems are better off
+  // with the register-staged kernel + split-K (the ring kernels have no split-K yet).
+  if (!g_dma_auto || a.K < 256) return 0;
+  if (t128 >= 400) return 128;
+  if (t64 >= 768) return 64;
+  if (t64 >= 256 && a.K < 2048) return 64;
+  return 0;
 }
 
 int gemm_kch(const GemmArgs& a) {
@@ -433,7 +442,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   a.vec_ok = !(a.ldc & 7) && !(a.sC1 & 7) && !(a.sC2 & 7) && (!a.R || (!(a.ldr & 7) && !(a.sR1 & 7) && !(a.sR2 & 7))) &&
              (!a.rowbias || !(a.N & 7)) && !((uintptr_t)a.C & 15) && !((uintptr_t)a.R & 15) && !((uintptr_t)a.bias & 15);
   const int Z = a.Z1 * a.Z2;
-  if (gemm_uses_dma(dtype, a)) { a.splitk = 1; return launch_gemm_dma(a, st); }
+  if (int dt = gemm_uses_dma(dtype, a)) { a.splitk = 1; return launch_gemm_dma(a, dt, st); }
   a.splitk = gemm_pick_splitk(dtype, a);
   if (gemm_uses_big_tile(a)) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);

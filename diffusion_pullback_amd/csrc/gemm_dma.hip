@@ -29,12 +29,13 @@ __device__ inline bf16x8 lds_read_b128(unsigned addr) {
   return v;
 }
 
-template <int S>
+template <int BM, int BN, int S>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
-  constexpr int BM = 128, BN = 128, BK = 32, CH = 8;
+  constexpr int BK = 32, CH = 8;
+  constexpr int NIA = BM / 64, NIB = BN / 64;                          // DMA wave-instructions per stage per wave (A, B)
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;     // 8 KiB + 8 KiB
   constexpr int P = S - 1;                                             // K-steps in flight
-  constexpr int WM = 64, WN = 64, TM = 2, TN = 2, SLD = WN + 4;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, SLD = WN + 4;
   __shared__ __attribute__((aligned(16))) char smem[S * STAGE];
   static_assert(S * STAGE >= 4 * 32 * SLD * 4, "epilogue staging must fit in the ring");
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
@@ -55,13 +56,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   const bf16* zero = (const bf16*)p.zeros;
 
   // ---- DMA slots of this lane: wave instruction i covers LDS chunks (wave*2+i)*64 + lane of the A (B) tile
-  const bf16* a_base[2];
-  const bf16* b_base[2];
-  int a_oy[2], a_ox[2], kc[2], tap[2], cc[2];
-  bool a_ok[2], b_ok[2];
+  // (A and B tiles have the same height here, so one slot index serves both)
+  static_assert(BM == BN, "square tiles only");
+  constexpr int NI = NIA;
+  const bf16* a_base[NI];
+  const bf16* b_base[NI];
+  int a_oy[NI], a_ox[NI], kc[NI], tap[NI], cc[NI];
+  bool a_ok[NI], b_ok[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pos = (wave * 2 + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
+  for (int i = 0; i < NI; ++i) {
+    const int pos = (wave * NI + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
     const int kq = phys ^ ((row >> 2) & 3);
     kc[i] = kq * CH;
     const int m = m0 + row, n = n0 + row;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   auto issue = [&](int slot) {
     char* st = smem + slot * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const bf16* src = zero;
       bool ok = a_ok[i] && kc[i] < p.K;
       if (p.gather == GATHER_NONE) {
@@ -110,15 +114,15 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
         }
         if (ok) src = a_base[i] + ((long)iy * p.W + ix) * p.lda + cc[i];
       }
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * 2 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * NI + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const bf16* src = (b_ok[i] && kc[i] < p.K) ? b_base[i] + kc[i] : zero;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + A_BYTES + (wave * 2 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + A_BYTES + (wave * NI + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       kc[i] += BK;
       if (p.gather != GATHER_NONE) {
         cc[i] += BK;
@@ -157,10 +161,23 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
     if (s < nk) issue(s);
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt landed for this wave: everything issued after it may still be in flight (4 DMA instructions per stage)
-    const int later = min(P - 1, nk - 1 - kt);
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int later = min(P - 1, nk - 1 - kt);     // stages issued after stage kt that may still be in flight
+    if constexpr (NI == 2) {                       // 4 DMA instructions per stage
+      if (later >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (later == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {                                       // 2 DMA instructions per stage
+      if (later >= 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (later == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    static_assert(P - 1 <= (NI == 2 ? 4 : 6), "add vmcnt cases for a deeper ring");
     __builtin_amdgcn_s_barrier();          // ... and for every other wave; also: stage kt-1 is fully consumed
     if (kt + P < nk) issue((kt + P) % S);  // refill the slot stage kt-1 occupied
     const unsigned sb = lds0 + (kt % S) * STAGE;
@@ -248,9 +265,17 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   }
 }
 
-int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
-  dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, 1);
-  hipLaunchKernelGGL((gemm_dma_kernel<4>), grid, dim3(256), 0, st, a);
+int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st) {
+  if (tile == 128) {
+    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, 1);
+    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4>), grid, dim3(256), 0, st, a);
+  } else if (tile == 64) {
+    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, 1);
+    hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 4>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, 1);
+    hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 6>), grid, dim3(256), 0, st, a);
+  }
   DPB_CHECK(hipGetLastError());
   return 0;
 }
