@@ -167,15 +167,23 @@ def main():
         eng.iterate(tap, V0_d.clone(), 1)
         if os.environ.get("DPB_PROFILE_CSV"):
             eng.profile_dump(os.environ["DPB_PROFILE_CSV"])
-        kinds = {"gemm_kernel<%s,64,64,4>" % dname: eng.profile_read(0), "gemm_dma_kernel<4> (bf16 128x128 LDS ring)": eng.profile_read(2)}
+        tname = "float" if dname == "fp32" else "bf16"
+        kinds = {"gemm_kernel<%s,64,64,4>" % tname: eng.profile_read(0), "gemm_dma_kernel<128,128,4>": eng.profile_read(2),
+                 "gemm_dma_kernel<64,64,4>": eng.profile_read(3)}
         eng.profile(False)
         dom = max(kinds, key=lambda n: kinds[n][1])                      # dominant = most GPU time
         n_d, ms_d, fl_d = kinds[dom]
         ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
         mac = MAC_G.get(a.workload)
         gemm_ms = sum(v[1] for v in kinds.values())
+        traffic = None                                                  # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_sd15_mid_k5_bf16.json")
+        if a.workload == "sd15" and dname == "bf16" and S == 1 and os.path.exists(pmc):
+            ent = json.load(open(pmc))["kernels"].get(dom)
+            if ent and ent.get("write_kb_per_launch") is not None:
+                traffic = (2.0 * ent["fetch_kb_per_launch"] + ent["write_kb_per_launch"]) * 1024.0
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach / PEAK[dname],
-                           "traffic": None, "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
+                           "traffic": traffic, "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic_*.json)", "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
                            "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * v[1] / max(v[0], 1),
                                                     "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},
                            "gemm_time_share_of_step": gemm_ms / (res["ms_per_step"] * S),
