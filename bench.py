@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--workload", default="sd15", choices=["sd15", "ddpm256", "toy"])
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--op", default="mid", choices=["down", "mid", "up"], help="feature tap (BASELINE config 5 sweeps down/up 0..3)")
+    ap.add_argument("--block-idx", type=int, default=0)
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="x_t samples advanced together per GPU (independent bases, shared weight stream); steps must be a multiple")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -48,7 +50,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_workload(name, dtype, device, k, spg):
+def make_workload(name, dtype, device, k, spg, tap=("mid", 0)):
     """-> (net, get_h_oracle, samples x [S,...], t, ctx, V0[k,N], tap)"""
     from diffusion_pullback_amd import PullbackUNet
     g = torch.Generator().manual_seed(0)
@@ -56,25 +58,25 @@ def make_workload(name, dtype, device, k, spg):
         from diffusion_pullback_amd import configs as cf
         cfg = cf.SD15 if name == "sd15" else cf.SDConfig(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False),
                                                                   up_attn=(False, True), heads=(2, 2), cross_dim=64, sample_size=16, ctx_len=77)
-        enc = ("time_embedding", "conv_in", "down_blocks", "mid_block")
+        enc = ("time_embedding", "conv_in", "down_blocks", "mid_block") if tap[0] != "up" else None
         params = cf.sd_init_params(cfg, seed=0, only_prefix=enc)
-        net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=("mid", 0), verbose=False)
+        net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=tap, verbose=False)
         t = 696.2727
         ctx = torch.randn(1, cfg.ctx_len, cfg.cross_dim, generator=g)          # fixed seeded "null" embedding
         shape = (cfg.in_channels, cfg.sample_size, cfg.sample_size)
         def oracle_get_h(zb):      # cpu_baseline leg only
             from oracle import unet_sd
-            return unet_sd.forward(params, cfg, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=("mid", 0))
+            return unet_sd.forward(params, cfg, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=tap)
     else:
         from diffusion_pullback_amd import configs as cf
         cfg = cf.CELEBA_HQ_256
         params = cf.ddpm_init_params(cfg, seed=0)
-        net = PullbackUNet("ddpm", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=("mid", 0), verbose=False)
+        net = PullbackUNet("ddpm", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=tap, verbose=False)
         t, ctx = 600.0, None
         shape = (cfg.in_channels, cfg.resolution, cfg.resolution)
         def oracle_get_h(xb):      # cpu_baseline leg only
             from oracle import unet_ddpm
-            return unet_ddpm.forward(params, cfg, xb, torch.tensor(t), stop=("mid", 0))
+            return unet_ddpm.forward(params, cfg, xb, torch.tensor(t), stop=tap)
     n_in = shape[0] * shape[1] * shape[2]
     V0 = torch.linalg.qr(torch.randn(n_in, k, generator=g))[0].T.contiguous()
     return net, oracle_get_h, shape, t, ctx, V0
@@ -98,8 +100,8 @@ def main():
     k = a.k
     S = a.samples_per_gpu
     assert a.steps % S == 0 and a.warmup % S == 0, "--steps and --warmup must be multiples of --samples-per-gpu"
-    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, S)
-    tap = ("mid", 0)
+    tap = (a.op, a.block_idx)
+    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, S, tap)
     eng = net.engine
 
     group = S * ITERS_PER_SAMPLE                      # steps per group of S concurrently advanced samples
@@ -155,7 +157,7 @@ def main():
         "config": {"workload": {"sd15": "BASELINE configs[2]: SD-v1.5 4x64x64 latent, no edit prompt (seeded null ctx[1,77,768]), mid-block h[1280,8,8], t=696.27",
                                 "ddpm256": "BASELINE configs[1]: CelebA-HQ DDPM 256x256 x[3,256,256], mid-block h[512,8,8], t=600",
                                 "toy": "toy SD-style net (plumbing check)"}[a.workload],
-                   "pca_rank": k, "iters_per_sample": ITERS_PER_SAMPLE, "samples_timed_per_gpu": n_samples, "samples_advanced_together": S,
+                   "tap": list(tap), "pca_rank": k, "iters_per_sample": ITERS_PER_SAMPLE, "samples_timed_per_gpu": n_samples, "samples_advanced_together": S,
                    "parallelism": f"{world} x independent samples, final all_gather of (u,s,vT)" if world > 1 else "single GPU"},
         "finite": finite, "s_top": [round(v, 5) for v in s.cpu().tolist()[:k]],
     }
@@ -174,7 +176,7 @@ def main():
         dom = max(kinds, key=lambda n: kinds[n][1])                      # dominant = most GPU time
         n_d, ms_d, fl_d = kinds[dom]
         ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
-        mac = MAC_G.get(a.workload)
+        mac = MAC_G.get(a.workload) if tap == ("mid", 0) else None
         gemm_ms = sum(v[1] for v in kinds.values())
         traffic = None                                                  # HBM bytes per launch of the dominant kernel from the committed PMC passes
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_sd15_mid_k5_bf16.json")
