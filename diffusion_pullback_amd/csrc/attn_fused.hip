@@ -125,7 +125,7 @@ struct FusedArgs {
   const bf16 *gO, *gOT;               // cotangent of the output [nt][L][C], gO^T [nt][H][d][L]
   bf16 *gQ, *gK, *gV;                 // cotangent outputs [nt][L][C]
   int accQ, accK, accV;               // accumulate into existing cotangents
-  int L, C, H, kps;
+  int L, C, Co, H, kps;               // C: row stride of Q/K/V-like tensors, Co: row stride of O-like tensors
   float scale;
 };
 
@@ -206,8 +206,9 @@ __global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
   }
   delta += __shfl_xor(delta, 32, 64);
   // dO[q][dcol] = acc - delta * O[q][dcol];  lane owns query q, register r <-> dcol = d*32 + (r&3) + 8*(r>>2) + 4*lhi
-  const bf16* Op = a.O + b * LC + (long)q * a.C + h * D;
-  bf16* dOp = a.dO + j * LC + (long)q * a.C + h * D;
+  const long LCo = (long)a.L * a.Co;
+  const bf16* Op = a.O + b * LCo + (long)q * a.Co + h * D;
+  bf16* dOp = a.dO + j * LCo + (long)q * a.Co + h * D;
 #pragma unroll
   for (int d = 0; d < F::ND; ++d)
 #pragma unroll
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
   const bf16* KTp = a.KT + ((long)b * a.H + h) * D * a.L;
   bf16x8 qf[F::NS], gof[F::NS], of[F::NS];
   load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
-  load_outer_frags<D>(a.gO + j * LC + (long)q * a.C + h * D, gof, lhi);
-  load_outer_frags<D>(a.O + b * LC + (long)q * a.C + h * D, of, lhi);
+  const long LCo = (long)a.L * a.Co;
+  load_outer_frags<D>(a.gO + j * LCo + (long)q * a.Co + h * D, gof, lhi);
+  load_outer_frags<D>(a.O + b * LCo + (long)q * a.Co + h * D, of, lhi);
   float Dq = 0.f;   // D_q = gO_q . O_q  (each lane holds half of the columns)
 #pragma unroll
   for (int stp = 0; stp < F::NS; ++stp) {
@@ -328,8 +330,9 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(Fus
   const int key = blockIdx.x * 128 + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
-  const bf16* Op = a.O + b * LC + h * D;
-  const bf16* gOp = a.gO + j * LC + h * D;
+  const long LCo = (long)a.L * a.Co;
+  const bf16* Op = a.O + b * LCo + h * D;
+  const bf16* gOp = a.gO + j * LCo + h * D;
   const bf16* QTp = a.QT + ((long)b * a.H + h) * D * a.L;
   const bf16* gOTp = a.gOT + ((long)j * a.H + h) * D * a.L;
   const float* stp_ = a.stats + ((long)b * a.H + h) * a.L * 2;
@@ -353,15 +356,15 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(Fus
       float dq = 0.f;
       for (int c = 0; c < D; c += 8) {
         float g8[8], o8[8];
-        Vec<bf16>::load(gOp + (long)qq * a.C + c, g8);
-        Vec<bf16>::load(Op + (long)qq * a.C + c, o8);
+        Vec<bf16>::load(gOp + (long)qq * a.Co + c, g8);
+        Vec<bf16>::load(Op + (long)qq * a.Co + c, o8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq += g8[e] * o8[e];
       }
       st2 = dq;
     }
   };
-  fetch_row<D>(Qp, a.C, rQ, tid); fetch_row<D>(gOp, a.C, rgO, tid); fetch_t<D>(QTp, a.L, rQT, tid); fetch_t<D>(gOTp, a.L, rgOT, tid);
+  fetch_row<D>(Qp, a.C, rQ, tid); fetch_row<D>(gOp, a.Co, rgO, tid); fetch_t<D>(QTp, a.L, rQT, tid); fetch_t<D>(gOTp, a.L, rgOT, tid);
   fetch_stats(0);
   for (int q0 = 0; q0 < a.L; q0 += F::BI) {
     __syncthreads();
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(Fus
     __syncthreads();
     if (q0 + F::BI < a.L) {
       const int q1 = q0 + F::BI;
-      fetch_row<D>(Qp + (long)q1 * a.C, a.C, rQ, tid); fetch_row<D>(gOp + (long)q1 * a.C, a.C, rgO, tid);
+      fetch_row<D>(Qp + (long)q1 * a.C, a.C, rQ, tid); fetch_row<D>(gOp + (long)q1 * a.Co, a.Co, rgO, tid);
       fetch_t<D>(QTp + q1, a.L, rQT, tid); fetch_t<D>(gOTp + q1, a.L, rgOT, tid);
       fetch_stats(q1);
     }
@@ -475,7 +478,7 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
   a.dQ = (const bf16*)f.dQ; a.dK = (const bf16*)f.dK; a.dV = (const bf16*)f.dV; a.dVT = (const bf16*)f.dVT; a.dO = (bf16*)f.dO;
   a.gO = (const bf16*)f.gO; a.gOT = (const bf16*)f.gOT; a.gQ = (bf16*)f.gQ; a.gK = (bf16*)f.gK; a.gV = (bf16*)f.gV;
   a.accQ = f.accQ; a.accK = f.accK; a.accV = f.accV;
-  a.L = f.L; a.C = f.C; a.H = f.H; a.kps = f.kps; a.scale = f.scale;
+  a.L = f.L; a.C = f.C; a.Co = f.Co; a.H = f.H; a.kps = f.kps; a.scale = f.scale;
   return a;
 }
 

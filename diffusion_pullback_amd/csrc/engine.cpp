@@ -47,6 +47,7 @@ struct Buf {
 struct AttnPlan {            // per attention op, persisted from the primal pass
   int heads = 0, d = 0, Lq = 0, Lk = 0, Lqp = 0, Lkp = 0;
   bool kv_const = false, fused = false;
+  int oq = 0, ok = 0, ov = 0;                      // column offsets of q / k / v inside their buffers (fused QKV projection)
   size_t P = 0, PT = 0, KT = 0, VT = 0, QT = 0, stats = 0;   // offsets
 };
 
@@ -330,15 +331,33 @@ int concat_run(dpb_engine* e, const Op& op, int mode, int n) {
 }
 
 // ------------------------------------------------------------------ attention (materialised scores)
+// Operand addressing: q / k / v may be column windows of wider buffers (fused QKV projection: one [rows][3C] buffer),
+// so every operand has its own row stride (ld*) and column offset (o*); the output buffer is [rows][C].
+struct AttnPtrs {
+  const char *Q, *K, *V; char* O;
+  int ldq, ldk, ldv, ldo;
+};
+static AttnPtrs attn_ptrs(dpb_engine* e, const dpb_op_desc& d, const AttnPlan& p, int which /*0 primal, 1 tangent, 2 cotangent*/) {
+  AttnPtrs a;
+  auto base = [&](int b) { return which == 0 ? e->P(b) : which == 1 ? e->T(b) : e->G(b); };
+  a.ldq = e->bufs[d.in0].C; a.ldk = e->bufs[d.in1].C; a.ldv = e->bufs[d.in2].C; a.ldo = e->bufs[d.out].C;
+  a.Q = base(d.in0) + (size_t)p.oq * e->es;
+  a.K = (which == 0 || !p.kv_const) ? base(d.in1) + (size_t)p.ok * e->es : nullptr;
+  a.V = (which == 0 || !p.kv_const) ? base(d.in2) + (size_t)p.ov * e->es : nullptr;
+  a.O = base(d.out);
+  return a;
+}
+
 int attn_primal(dpb_engine* e, const Op& op, int B) {
   const dpb_op_desc& d = op.d;
   const AttnPlan& p = e->plans[op.attn];
-  const int C = p.heads * p.d, H = p.heads;
+  const int H = p.heads;
   const float scale = 1.f / sqrtf((float)p.d);
   char* ws = e->ws;
+  const AttnPtrs x = attn_ptrs(e, d, p, 0);
   GemmArgs g;   // S = scale * Q K^T
-  g.A = e->P(d.in0); g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
-  g.B = e->P(d.in1); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d;
+  g.A = x.Q; g.lda = x.ldq; g.sA1 = (long)p.Lq * x.ldq; g.sA2 = p.d;
+  g.B = x.K; g.ldb = x.ldk; g.sB1 = (long)p.Lk * x.ldk; g.sB2 = p.d;
   g.C = ws + p.P; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
   g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = B; g.Z2 = H; g.alpha = scale;
   if (int r = gemm(e, g)) return r;
@@ -349,49 +368,56 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
   }
   if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
   // V^T, K^T per head ([d][Lkp], zero padded)
-  if (int r = launch_transpose(e->dtype, e->P(d.in2), ws + p.VT, B, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
-  if (int r = launch_transpose(e->dtype, e->P(d.in1), ws + p.KT, B, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+  if (int r = launch_transpose(e->dtype, x.V, ws + p.VT, B, H, (long)p.Lk * x.ldv, p.d, p.Lk, p.d, x.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+  if (int r = launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
   GemmArgs o;   // O = P V
   o.A = ws + p.P; o.lda = p.Lkp; o.sA1 = (long)H * p.Lq * p.Lkp; o.sA2 = (long)p.Lq * p.Lkp;
   o.B = ws + p.VT; o.ldb = p.Lkp; o.sB1 = (long)H * p.d * p.Lkp; o.sB2 = (long)p.d * p.Lkp;
-  o.C = e->P(d.out); o.ldc = C; o.sC1 = (long)p.Lq * C; o.sC2 = p.d;
+  o.C = x.O; o.ldc = x.ldo; o.sC1 = (long)p.Lq * x.ldo; o.sC2 = p.d;
   o.M = p.Lq; o.N = p.d; o.K = p.Lkp; o.Z1 = B; o.Z2 = H;
   if (int r = gemm(e, o)) return r;
   if (!p.kv_const) {
     e->n_launch += 2;
-    if (int r = launch_transpose(e->dtype, ws + p.P, ws + p.PT, B * H, 1, (long)p.Lq * p.Lkp, 0, p.Lq, p.Lk, p.Lkp, p.Lqp, (long)p.Lk * p.Lqp, e->stream)) return r;
-    if (int r = launch_transpose(e->dtype, e->P(d.in0), ws + p.QT, B, H, (long)p.Lq * C, p.d, p.Lq, p.d, C, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+    if (!p.fused)
+      if (int r = launch_transpose(e->dtype, ws + p.P, ws + p.PT, B * H, 1, (long)p.Lq * p.Lkp, 0, p.Lq, p.Lk, p.Lkp, p.Lqp, (long)p.Lk * p.Lqp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, x.Q, ws + p.QT, B, H, (long)p.Lq * x.ldq, p.d, p.Lq, p.d, x.ldq, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
   }
   return 0;
+}
+
+static void fill_fused(dpb_engine* e, const AttnPlan& p, const AttnPtrs& x, FusedAttnArgs& f, int kps, float scale) {
+  char* ws = e->ws;
+  f.Q = x.Q; f.K = x.K; f.V = x.V; f.O = x.O; f.VT = ws + p.VT; f.KT = ws + p.KT; f.QT = ws + p.QT;
+  f.stats = (const float*)(ws + p.stats);
+  f.L = p.Lq; f.C = x.ldq; f.Co = x.ldo; f.H = p.heads; f.d = p.d; f.kps = kps; f.scale = scale;
 }
 
 int attn_tangent(dpb_engine* e, const Op& op, int nt) {
   const dpb_op_desc& d = op.d;
   const AttnPlan& p = e->plans[op.attn];
-  const int C = p.heads * p.d, H = p.heads, kps = nt / e->cur_batch;
+  const int H = p.heads, kps = nt / e->cur_batch;
   const float scale = 1.f / sqrtf((float)p.d);
   char* ws = e->ws;
   char* S1 = ws + e->S1;
+  const AttnPtrs x = attn_ptrs(e, d, p, 0), t = attn_ptrs(e, d, p, 1);
   if (p.fused) {
     char* T1 = ws + e->T1;
     e->n_launch += 2;
-    if (int r = launch_transpose(e->dtype, e->T(d.in2), T1, nt, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, t.V, T1, nt, H, (long)p.Lk * t.ldv, p.d, p.Lk, p.d, t.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
     FusedAttnArgs f;
-    f.Q = e->P(d.in0); f.K = e->P(d.in1); f.V = e->P(d.in2); f.O = e->P(d.out); f.VT = ws + p.VT; f.KT = ws + p.KT; f.QT = ws + p.QT;
-    f.stats = (const float*)(ws + p.stats);
-    f.dQ = e->T(d.in0); f.dK = e->T(d.in1); f.dV = e->T(d.in2); f.dVT = T1; f.dO = e->T(d.out);
-    f.L = p.Lq; f.C = C; f.H = H; f.d = p.d; f.kps = kps; f.scale = scale;
+    fill_fused(e, p, x, f, kps, scale);
+    f.dQ = t.Q; f.dK = t.K; f.dV = t.V; f.dVT = T1; f.dO = t.O;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 5 * nt * H;
     return launch_attn_jvp_fused(f, nt, e->stream);
   }
   GemmArgs g;   // dS = scale * dQ K^T
-  g.A = e->T(d.in0); g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
-  g.B = e->P(d.in1); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
+  g.A = t.Q; g.lda = t.ldq; g.sA1 = (long)p.Lq * t.ldq; g.sA2 = p.d;
+  g.B = x.K; g.ldb = x.ldk; g.sB1 = (long)p.Lk * x.ldk; g.sB2 = p.d; g.divB = kps;
   g.C = S1; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
   g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = nt; g.Z2 = H; g.alpha = scale;
   if (!p.kv_const) {   // + scale * Q dK^T in the same launch (second operand pair)
-    g.A2 = e->P(d.in0); g.lda2 = C; g.sA21 = (long)p.Lq * C; g.sA22 = p.d; g.divA2 = kps;
-    g.B2 = e->T(d.in1); g.ldb2 = C; g.sB21 = (long)p.Lk * C; g.sB22 = p.d; g.divB2 = 1;
+    g.A2 = x.Q; g.lda2 = x.ldq; g.sA21 = (long)p.Lq * x.ldq; g.sA22 = p.d; g.divA2 = kps;
+    g.B2 = t.K; g.ldb2 = t.ldk; g.sB21 = (long)p.Lk * t.ldk; g.sB22 = p.d; g.divB2 = 1;
     g.K2 = p.d;
   }
   if (int r = gemm(e, g)) return r;
@@ -400,12 +426,12 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
   GemmArgs o;   // dO = dP V
   o.A = S1; o.lda = p.Lkp; o.sA1 = (long)H * p.Lq * p.Lkp; o.sA2 = (long)p.Lq * p.Lkp;
   o.B = ws + p.VT; o.ldb = p.Lkp; o.sB1 = (long)H * p.d * p.Lkp; o.sB2 = (long)p.d * p.Lkp; o.divB = kps;
-  o.C = e->T(d.out); o.ldc = C; o.sC1 = (long)p.Lq * C; o.sC2 = p.d;
+  o.C = t.O; o.ldc = t.ldo; o.sC1 = (long)p.Lq * t.ldo; o.sC2 = p.d;
   o.M = p.Lq; o.N = p.d; o.K = p.Lkp; o.Z1 = nt; o.Z2 = H;
   if (!p.kv_const) {   // + P dV in the same launch
     char* T1 = ws + e->T1;
     e->n_launch++;
-    if (int r = launch_transpose(e->dtype, e->T(d.in2), T1, nt, H, (long)p.Lk * C, p.d, p.Lk, p.d, C, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, t.V, T1, nt, H, (long)p.Lk * t.ldv, p.d, p.Lk, p.d, t.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
     o.A2 = ws + p.P; o.lda2 = p.Lkp; o.sA21 = (long)H * p.Lq * p.Lkp; o.sA22 = (long)p.Lq * p.Lkp; o.divA2 = kps;
     o.B2 = T1; o.ldb2 = p.Lkp; o.sB21 = (long)H * p.d * p.Lkp; o.sB22 = (long)p.d * p.Lkp; o.divB2 = 1;
     o.K2 = p.Lkp;
@@ -416,30 +442,31 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
 int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   const dpb_op_desc& d = op.d;
   const AttnPlan& p = e->plans[op.attn];
-  const int C = p.heads * p.d, H = p.heads, kps = nt / e->cur_batch;
+  const int H = p.heads, kps = nt / e->cur_batch;
   const float scale = 1.f / sqrtf((float)p.d);
   char* ws = e->ws;
   char* S1 = ws + e->S1;
   float* Dv = (float*)(ws + e->Dv);
-  const char* gO = e->G(d.out);
+  const AttnPtrs x = attn_ptrs(e, d, p, 0), c = attn_ptrs(e, d, p, 2);
+  const char* gO = c.O;
+  // first-write / accumulate flags, read up front: q, k, v may be windows of ONE buffer (fused QKV)
+  const int accQ = e->ginit[d.in0], accK = p.kv_const ? 0 : e->ginit[d.in1], accV = p.kv_const ? 0 : e->ginit[d.in2];
   if (p.fused) {
     char* T1 = ws + e->T1;
     e->n_launch += 3;
-    if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * C, p.d, p.Lq, p.d, C, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * c.ldo, p.d, p.Lq, p.d, c.ldo, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
     FusedAttnArgs f;
-    f.Q = e->P(d.in0); f.K = e->P(d.in1); f.V = e->P(d.in2); f.O = e->P(d.out); f.VT = ws + p.VT; f.KT = ws + p.KT; f.QT = ws + p.QT;
-    f.stats = (const float*)(ws + p.stats);
-    f.gO = gO; f.gOT = T1; f.gQ = e->G(d.in0); f.gK = e->G(d.in1); f.gV = e->G(d.in2);
-    f.accQ = e->ginit[d.in0]; f.accK = e->ginit[d.in1]; f.accV = e->ginit[d.in2];
-    f.L = p.Lq; f.C = C; f.H = H; f.d = p.d; f.kps = kps; f.scale = scale;
+    fill_fused(e, p, x, f, kps, scale);
+    f.gO = gO; f.gOT = T1; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V;
+    f.accQ = accQ; f.accK = accK; f.accV = accV;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;
     if (int r = launch_attn_adj_fused(f, nt, e->stream)) return r;
     e->ginit[d.in0] = e->ginit[d.in1] = e->ginit[d.in2] = 1;
     return 0;
   }
   GemmArgs g;   // gP = gO V^T
-  g.A = gO; g.lda = C; g.sA1 = (long)p.Lq * C; g.sA2 = p.d;
-  g.B = e->P(d.in2); g.ldb = C; g.sB1 = (long)p.Lk * C; g.sB2 = p.d; g.divB = kps;
+  g.A = gO; g.lda = c.ldo; g.sA1 = (long)p.Lq * c.ldo; g.sA2 = p.d;
+  g.B = x.V; g.ldb = x.ldv; g.sB1 = (long)p.Lk * x.ldv; g.sB2 = p.d; g.divB = kps;
   g.C = S1; g.ldc = p.Lkp; g.sC1 = (long)H * p.Lq * p.Lkp; g.sC2 = (long)p.Lq * p.Lkp;
   g.M = p.Lq; g.N = p.Lk; g.K = p.d; g.Z1 = nt; g.Z2 = H;
   if (int r = gemm(e, g)) return r;
@@ -448,9 +475,9 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   GemmArgs q;   // gQ (+)= scale * gS K
   q.A = S1; q.lda = p.Lkp; q.sA1 = (long)H * p.Lq * p.Lkp; q.sA2 = (long)p.Lq * p.Lkp;
   q.B = ws + p.KT; q.ldb = p.Lkp; q.sB1 = (long)H * p.d * p.Lkp; q.sB2 = (long)p.d * p.Lkp; q.divB = kps;
-  q.C = e->G(d.in0); q.ldc = C; q.sC1 = (long)p.Lq * C; q.sC2 = p.d;
+  q.C = (void*)c.Q; q.ldc = c.ldq; q.sC1 = (long)p.Lq * c.ldq; q.sC2 = p.d;
   q.M = p.Lq; q.N = p.d; q.K = p.Lkp; q.Z1 = nt; q.Z2 = H; q.alpha = scale;
-  q.accumulate = e->ginit[d.in0];
+  q.accumulate = accQ;
   if (int r = gemm(e, q)) return r;
   e->ginit[d.in0] = 1;
   if (p.kv_const) return 0;
@@ -458,18 +485,17 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   char* S2 = ws + e->S2;
   e->n_launch += 2;
   // gO^T per head [d][Lqp]
-  if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * C, p.d, p.Lq, p.d, C, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+  if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * c.ldo, p.d, p.Lq, p.d, c.ldo, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
   GemmArgs v;   // gV (+)= P^T gO
   v.A = ws + p.PT; v.lda = p.Lqp; v.sA1 = (long)H * p.Lk * p.Lqp; v.sA2 = (long)p.Lk * p.Lqp; v.divA = kps;
   v.B = T1; v.ldb = p.Lqp; v.sB1 = (long)H * p.d * p.Lqp; v.sB2 = (long)p.d * p.Lqp;
-  v.C = e->G(d.in2); v.ldc = C; v.sC1 = (long)p.Lk * C; v.sC2 = p.d;
+  v.C = (void*)c.V; v.ldc = c.ldv; v.sC1 = (long)p.Lk * c.ldv; v.sC2 = p.d;
   v.M = p.Lk; v.N = p.d; v.K = p.Lqp; v.Z1 = nt; v.Z2 = H;
-  v.accumulate = e->ginit[d.in2];
+  v.accumulate = accV;
   if (int r = gemm(e, v)) return r;
-  e->ginit[d.in2] = 1;
   GemmArgs t;   // gP^T = V gO^T
-  t.A = e->P(d.in2); t.lda = C; t.sA1 = (long)p.Lk * C; t.sA2 = p.d; t.divA = kps;
-  t.B = gO; t.ldb = C; t.sB1 = (long)p.Lq * C; t.sB2 = p.d;
+  t.A = x.V; t.lda = x.ldv; t.sA1 = (long)p.Lk * x.ldv; t.sA2 = p.d; t.divA = kps;
+  t.B = gO; t.ldb = c.ldo; t.sB1 = (long)p.Lq * c.ldo; t.sB2 = p.d;
   t.C = S2; t.ldc = p.Lqp; t.sC1 = (long)H * p.Lk * p.Lqp; t.sC2 = (long)p.Lk * p.Lqp;
   t.M = p.Lk; t.N = p.Lq; t.K = p.d; t.Z1 = nt; t.Z2 = H;
   if (int r = gemm(e, t)) return r;
@@ -477,11 +503,11 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   GemmArgs k;   // gK (+)= scale * gS^T Q
   k.A = S2; k.lda = p.Lqp; k.sA1 = (long)H * p.Lk * p.Lqp; k.sA2 = (long)p.Lk * p.Lqp;
   k.B = ws + p.QT; k.ldb = p.Lqp; k.sB1 = (long)H * p.d * p.Lqp; k.sB2 = (long)p.d * p.Lqp; k.divB = kps;
-  k.C = e->G(d.in1); k.ldc = C; k.sC1 = (long)p.Lk * C; k.sC2 = p.d;
+  k.C = (void*)c.K; k.ldc = c.ldk; k.sC1 = (long)p.Lk * c.ldk; k.sC2 = p.d;
   k.M = p.Lk; k.N = p.d; k.K = p.Lqp; k.Z1 = nt; k.Z2 = H; k.alpha = scale;
-  k.accumulate = e->ginit[d.in1];
+  k.accumulate = accK;
   if (int r = gemm(e, k)) return r;
-  e->ginit[d.in1] = 1;
+  e->ginit[d.in1] = e->ginit[d.in2] = 1;
   return 0;
 }
 
@@ -561,8 +587,12 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       c = c && e->bufs[d.in2].is_const;
       AttnPlan p;
       p.heads = d.ip[0];
-      if (p.heads < 1 || e->bufs[d.in0].C % p.heads) return bad("channels not divisible by heads", i);
-      p.d = e->bufs[d.in0].C / p.heads;
+      p.oq = d.ip[1]; p.ok = d.ip[2]; p.ov = d.ip[3];
+      const int Cattn = e->bufs[d.out].C;
+      if (p.heads < 1 || Cattn % p.heads) return bad("channels not divisible by heads", i);
+      p.d = Cattn / p.heads;
+      if (p.oq % 8 || p.ok % 8 || p.ov % 8 || p.oq + Cattn > e->bufs[d.in0].C || p.ok + Cattn > e->bufs[d.in1].C || p.ov + Cattn > e->bufs[d.in2].C)
+        return bad("bad q/k/v column window", i);
       if (p.d % 8) return bad("head dim must be a multiple of 8", i);
       p.Lq = e->bufs[d.in0].rows; p.Lk = e->bufs[d.in1].rows;
       p.Lqp = round8(p.Lq); p.Lkp = round8(p.Lk);
@@ -608,7 +638,8 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       s1 = std::max(s1, (size_t)e->maxT * H * p.Lq * p.Lkp * es);
       size_t lmax = std::max(p.Lqp, p.Lkp);
       t1 = std::max(t1, (size_t)e->maxT * H * p.d * lmax * es);
-      p.fused = fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN");
+      p.fused = fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN") &&
+                e->bufs[d.in0].C == e->bufs[d.in1].C && e->bufs[d.in0].C == e->bufs[d.in2].C;
       if (p.fused) p.stats = take((size_t)e->maxB * H * p.Lq * 2 * sizeof(float));
       if (!p.kv_const) {
         p.PT = take((size_t)e->maxB * H * p.Lk * p.Lqp * es);

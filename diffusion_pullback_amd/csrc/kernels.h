@@ -88,7 +88,7 @@ struct FusedAttnArgs {
   const void *dQ = nullptr, *dK = nullptr, *dV = nullptr, *dVT = nullptr; void* dO = nullptr;
   const void *gO = nullptr, *gOT = nullptr; void *gQ = nullptr, *gK = nullptr, *gV = nullptr;
   int accQ = 0, accK = 0, accV = 0;
-  int L = 0, C = 0, H = 0, d = 0, kps = 1;
+  int L = 0, C = 0, Co = 0, H = 0, d = 0, kps = 1;   // C: row stride of q/k/v (and their tangents / cotangents), Co: of o
   float scale = 1.f;
 };
 int fused_attention_supported(int dtype, int d, int L, int kv_const);

@@ -96,11 +96,20 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
         }
       }
       if (STATS) {
+        // a 16-byte chunk spans at most a few groups: combine equal-group channels in registers first, so a thread
+        // issues one pair of LDS atomics per group it touches instead of one pair per channel
+        float g1 = s1[0], g2 = s2[0];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) {
-          atomicAdd(&lsum[grp[e] * 2], s1[e]);
-          atomicAdd(&lsum[grp[e] * 2 + 1], s2[e]);
+        for (int e = 1; e < CH; ++e) {
+          if (grp[e] != grp[e - 1]) {
+            atomicAdd(&lsum[grp[e - 1] * 2], g1);
+            atomicAdd(&lsum[grp[e - 1] * 2 + 1], g2);
+            g1 = 0.f; g2 = 0.f;
+          }
+          g1 += s1[e]; g2 += s2[e];
         }
+        atomicAdd(&lsum[grp[CH - 1] * 2], g1);
+        atomicAdd(&lsum[grp[CH - 1] * 2 + 1], g2);
       }
     }
   }

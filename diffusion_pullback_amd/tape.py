@@ -52,11 +52,14 @@ class Tape:
         self.keep.append(t)
         return t.data_ptr()
 
-    def _conv_w(self, name: str, cin_p: int, cout_p: int, need_adj: bool):
+    def _conv_w(self, name, cin_p: int, cout_p: int, need_adj: bool):
+        """``name`` may be a tuple of parameter names: their weights (and biases) are concatenated along Cout,
+        which fuses projections that read the same input (q/k/v) into one GEMM."""
         key = f"{name}|{cin_p}|{cout_p}|{need_adj}"
         if key in self._wcache:
             return self._wcache[key]
-        w = self.p[name + ".weight"].float()
+        names = name if isinstance(name, tuple) else (name,)
+        w = torch.cat([self.p[n + ".weight"].float() for n in names], dim=0)
         if w.dim() == 2:
             w = w[:, :, None, None]
         cout, cin, kh, kw = w.shape
@@ -68,7 +71,10 @@ class Tape:
             wa = torch.zeros(cin_p, kh, kw, cout_p)
             wa[:cin, :, :, :cout] = w.permute(1, 2, 3, 0)
             pa = self._dev(wa.reshape(cin_p, kh * kw * cout_p), self.dtype)
-        b = self.p.get(name + ".bias")
+        bs = [self.p.get(n + ".bias") for n in names]
+        b = None
+        if any(x is not None for x in bs):
+            b = torch.cat([x.float() if x is not None else torch.zeros(self.p[n + ".weight"].shape[0]) for x, n in zip(bs, names)])
         pb = self._dev(b.float(), torch.float32) if b is not None else 0
         self._wcache[key] = (pf, pa, pb)
         return pf, pa, pb
@@ -113,10 +119,12 @@ class Tape:
                  w=[self._dev(self.p[name + ".weight"], torch.float32), self._dev(self.p[name + ".bias"], torch.float32), 0, 0])
         return out
 
-    def attention(self, q: int, k: int, v: int, heads: int) -> int:
-        rows, c, _ = self.buffers[q]
+    def attention(self, q: int, k: int, v: int, heads: int, c: int = 0, offsets=(0, 0, 0)) -> int:
+        """q / k / v may be column windows (``offsets``) of wider buffers, e.g. one fused [rows][3C] projection."""
+        rows, cq, _ = self.buffers[q]
+        c = c or cq
         out = self.buf(rows, c)
-        self._op(kind=L.OP_ATTENTION, in0=q, in1=k, in2=v, out=out, ip=[heads] + [0] * 11)
+        self._op(kind=L.OP_ATTENTION, in0=q, in1=k, in2=v, out=out, ip=[heads, offsets[0], offsets[1], offsets[2]] + [0] * 8)
         return out
 
     def geglu(self, x: int) -> int:
@@ -167,10 +175,8 @@ def build_ddpm(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = Non
 
     def attn(pre, x, c, r):
         n = t.groupnorm(pre + ".norm", x, G, eps, False)
-        q = t.conv(pre + ".q", n, (r, r), c, ks=1)
-        k = t.conv(pre + ".k", n, (r, r), c, ks=1)
-        v = t.conv(pre + ".v", n, (r, r), c, ks=1)
-        a = t.attention(q, k, v, 1)
+        qkv = t.conv((pre + ".q", pre + ".k", pre + ".v"), n, (r, r), 3 * c, ks=1)      # fused projection: one GEMM, N = 3C
+        a = t.attention(qkv, qkv, qkv, 1, c, (0, c, 2 * c))
         return t.conv(pre + ".proj_out", a, (r, r), c, ks=1, res=x)
 
     nres = len(cfg.ch_mult)
@@ -249,15 +255,12 @@ def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None)
         h = t.conv(pre + ".proj_in", n, (r, r), c, ks=1)
         tb = pre + ".transformer_blocks.0"
         z = t.layernorm(tb + ".norm1", h)
-        q = t.conv(tb + ".attn1.to_q", z, (r, r), c, ks=1)
-        k = t.conv(tb + ".attn1.to_k", z, (r, r), c, ks=1)
-        v = t.conv(tb + ".attn1.to_v", z, (r, r), c, ks=1)
-        h = t.conv(tb + ".attn1.to_out.0", t.attention(q, k, v, heads), (r, r), c, ks=1, res=h)
+        qkv = t.conv((tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"), z, (r, r), 3 * c, ks=1)   # fused q/k/v
+        h = t.conv(tb + ".attn1.to_out.0", t.attention(qkv, qkv, qkv, heads, c, (0, c, 2 * c)), (r, r), c, ks=1, res=h)
         z = t.layernorm(tb + ".norm2", h)
         q = t.conv(tb + ".attn2.to_q", z, (r, r), c, ks=1)
-        k = t.conv(tb + ".attn2.to_k", t.ctx, (1, 1), c, ks=1, need_adj=False)
-        v = t.conv(tb + ".attn2.to_v", t.ctx, (1, 1), c, ks=1, need_adj=False)
-        h = t.conv(tb + ".attn2.to_out.0", t.attention(q, k, v, heads), (r, r), c, ks=1, res=h)
+        kv = t.conv((tb + ".attn2.to_k", tb + ".attn2.to_v"), t.ctx, (1, 1), 2 * c, ks=1, need_adj=False)     # fused k/v of the context
+        h = t.conv(tb + ".attn2.to_out.0", t.attention(q, kv, kv, heads, c, (0, 0, c)), (r, r), c, ks=1, res=h)
         z = t.layernorm(tb + ".norm3", h)
         f = t.geglu(t.conv(tb + ".ff.net.0.proj", z, (r, r), 8 * c, ks=1))
         h = t.conv(tb + ".ff.net.2", f, (r, r), c, ks=1, res=h)
