@@ -391,13 +391,33 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
-  // >= ~2 tiles; below that the 64x64 ring wins if it still fills the chip; long-K under-filled problems are better off
-  // with the register-staged kernel + split-K (the ring kernels have no split-K yet).
+  // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
+  // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
-  if (t128 >= 400) return 128;
-  if (t64 >= 768) return 64;
-  if (t64 >= 256 && a.K < 2048) return 64;
+  if (t128 >= 400) return 128;                  // chip filled by 128x128 tiles
+  if (a.K >= 2048 && t128 >= 64) return 128;    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
+  if (t64 >= 256) return 64;
   return 0;
+}
+
+// split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
+int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
+  if (!a.slab) return 1;
+  const int T = tile == 128 ? 128 : 64;
+  const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
+  const int nk = (a.K + 31) / 32;
+  long s;
+  if (g_force_splitk) s = g_force_splitk;
+  else {
+    if (tiles >= 256 || nk < 64) return 1;      // only when CUs would idle and K is long enough to amortise the slabs
+    s = (1024 + tiles - 1) / tiles;
+    s = std::min<long>(s, nk / 12);             // keep >= 12 K steps per block (ring depth 3)
+    s = std::min<long>(s, 32);
+  }
+  s = std::min<long>(s, nk);
+  const long per = (long)a.M * a.N * a.Z1 * a.Z2 * 4;
+  if (s * per > (long)a.slab_bytes) s = (long)a.slab_bytes / per;
+  return (int)std::max<long>(s, 1);
 }
 
 int gemm_kch(const GemmArgs& a) {
@@ -442,7 +462,17 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   a.vec_ok = !(a.ldc & 7) && !(a.sC1 & 7) && !(a.sC2 & 7) && (!a.R || (!(a.ldr & 7) && !(a.sR1 & 7) && !(a.sR2 & 7))) &&
              (!a.rowbias || !(a.N & 7)) && !((uintptr_t)a.C & 15) && !((uintptr_t)a.R & 15) && !((uintptr_t)a.bias & 15);
   const int Z = a.Z1 * a.Z2;
-  if (int dt = gemm_uses_dma(dtype, a)) { a.splitk = 1; return launch_gemm_dma(a, dt, st); }
+  if (int dt = gemm_uses_dma(dtype, a)) {
+    a.splitk = gemm_pick_splitk_dma(a, dt);
+    if (int r = launch_gemm_dma(a, dt, st)) return r;
+    if (a.splitk > 1) {
+      long total = (long)a.M * a.N * Z;
+      unsigned g = (unsigned)std::min<long>((total + 255) / 256, 4096);
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+      DPB_CHECK(hipGetLastError());
+    }
+    return 0;
+  }
   a.splitk = gemm_pick_splitk(dtype, a);
   if (gemm_uses_big_tile(a)) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);

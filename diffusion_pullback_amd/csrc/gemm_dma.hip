@@ -55,6 +55,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   const bf16* R = p.R ? (const bf16*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 : nullptr;
   const bf16* zero = (const bf16*)p.zeros;
 
+  // K range of this block (split-K over blockIdx.z, in steps of BK)
+  const int nk_all = (p.K + BK - 1) / BK;
+  int kt_begin = 0, nk = nk_all;
+  if (p.splitk > 1) {
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    kt_begin = blockIdx.z * per;
+    nk = max(0, min(nk_all, kt_begin + per) - kt_begin);
+  }
   // ---- DMA slots of this lane: wave instruction i covers LDS chunks (wave*2+i)*64 + lane of the A (B) tile
   // (A and B tiles have the same height here, so one slot index serves both)
   static_assert(BM == BN, "square tiles only");
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   for (int i = 0; i < NI; ++i) {
     const int pos = (wave * NI + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
     const int kq = phys ^ ((row >> 2) & 3);
-    kc[i] = kq * CH;
+    kc[i] = kt_begin * BK + kq * CH;
     const int m = m0 + row, n = n0 + row;
     a_ok[i] = m < p.M;
     b_ok[i] = n < p.N;
@@ -155,7 +163,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
     for (int kk = 0; kk < 2; ++kk) fb[j][kk] = A_BYTES + row * 64 + (((kk * 2 + lhi) ^ sw) << 4);
   }
 
-  const int nk = (p.K + BK - 1) / BK;
 #pragma unroll
   for (int s = 0; s < P; ++s)
     if (s < nk) issue(s);
@@ -221,6 +228,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
       float v[8];
       Vec<float>::load(stage + row * SLD + c8 * 8, v);
       Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
+      if (p.splitk > 1) {                           // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
+        float* sp = p.slab + ((long)blockIdx.z * gridDim.y + blockIdx.y) * (long)p.M * p.N + (long)m * p.N + n;
+        if (n + 8 <= p.N && !(p.N & 3)) {
+          Vec<float>::store(sp, v);
+          Vec<float>::store(sp + 4, v + 4);
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) sp[e] = v[e];
+        }
+        continue;
+      }
       int smp = 0;
       if (p.rowbias) smp = (m / p.rows_per_sample) / p.rowbias_div;
       bf16* cp = C + (long)m * p.ldc + n;
@@ -266,14 +283,15 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
 }
 
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st) {
+  const int sk = a.splitk > 1 ? a.splitk : 1;
   if (tile == 128) {
-    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, 1);
+    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
     hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4>), grid, dim3(256), 0, st, a);
   } else if (tile == 64) {
-    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, 1);
+    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, sk);
     hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 4>), grid, dim3(256), 0, st, a);
   } else {
-    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, 1);
+    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, sk);
     hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 6>), grid, dim3(256), 0, st, a);
   }
   DPB_CHECK(hipGetLastError());

@@ -193,15 +193,16 @@ def test_dma_gemm_bitwise_equals_register_gemm():
                 e.primal(x, 1.0, None, "o")
                 return e.read("o").clone(), e.jvp("o", V).clone(), e.vjp("o", U).clone()
 
-            L.check(lib.dpb_debug_set(b"gemm_tile", 64)); L.check(lib.dpb_debug_set(b"gemm_splitk", 1))
-            ref = run()
-            assert all(torch.isfinite(r).all() for r in ref)
-            for code in (129, 65, 67):                      # 128x128 ring, 64x64 ring (4 and 6 stages)
-                L.check(lib.dpb_debug_set(b"gemm_tile", code))
-                for rep in range(4):
-                    got = run()
-                    for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
-                        assert torch.equal(a, b), f"case {(H, cin, cout, ks, stride, pad)} kernel {code} {name} rep {rep}: max |d| = {(a - b).abs().max().item():.3e}"
+            for sk in (1, 3):                                   # without and with split-K (same K partition in both kernels)
+                L.check(lib.dpb_debug_set(b"gemm_tile", 64)); L.check(lib.dpb_debug_set(b"gemm_splitk", sk))
+                ref = run()
+                assert all(torch.isfinite(r).all() for r in ref)
+                for code in (129, 65, 67):                      # 128x128 ring, 64x64 ring (4 and 6 stages)
+                    L.check(lib.dpb_debug_set(b"gemm_tile", code))
+                    for rep in range(3):
+                        got = run()
+                        for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
+                            assert torch.equal(a, b), f"case {(H, cin, cout, ks, stride, pad)} kernel {code} splitk {sk} {name} rep {rep}: max |d| = {(a - b).abs().max().item():.3e}"
     finally:
         L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
 
