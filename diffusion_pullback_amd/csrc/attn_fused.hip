@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
       float p[16], x[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = exp2f(c2 * s[r] - m2) * il;
+        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il;
         x[r] = p[r] * (a.scale * ds[r]);
         delta += x[r];
       }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
       }
       float gs[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gs[r] = exp2f(c2 * s[r] - m2) * il * (gp[r] - Dq);
+      for (int r = 0; r < 16; ++r) gs[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il * (gp[r] - Dq);
       bf16x8 gsb[2];
       pack_b(gs, gsb);
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(Fus
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        p[r] = exp2f(c2 * s[r] - sstat[0][qi]) * sstat[1][qi];
+        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - sstat[0][qi]) * sstat[1][qi];
         gs[r] = p[r] * (gp[r] - sstat[2][qi]);
       }
       bf16x8 pb[2], gsb[2];

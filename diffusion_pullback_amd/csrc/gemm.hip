@@ -346,11 +346,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-// sums the split-K fp32 slabs and applies the fused epilogue
+// sums the split-K fp32 slabs and applies the fused epilogue; 8 consecutive columns per thread when aligned
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
   const long MN = (long)p.M * p.N;
   const int Z = p.Z1 * p.Z2;
+  if (p.vec_ok && !(p.N & 7)) {
+    const int n8 = p.N >> 3;
+    const long total = (long)p.M * n8 * Z;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+      const int c = (int)(idx % n8);
+      const long mz = idx / n8;
+      const int m = (int)(mz % p.M), z = (int)(mz / p.M);
+      const int n = c * 8;
+      const long mn = (long)m * p.N + n;
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int s = 0; s < p.splitk; ++s) {
+        float t[8];
+        V8<float>::load(p.slab + ((long)s * Z + z) * MN + mn, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += t[e];
+      }
+      const int z1 = z / p.Z2, z2 = z % p.Z2;
+      float b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+      if (p.bias) {
+        V8<float>::load(p.bias + n, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      }
+      if (p.rowbias) {
+        V8<T>::load((const T*)p.rowbias + (long)((m / p.rows_per_sample) / p.rowbias_div) * p.N + n, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      }
+      if (p.R) {
+        V8<T>::load((const T*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 + (long)m * p.ldr + n, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      }
+      T* cp = (T*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2 + (long)m * p.ldc + n;
+      if (p.accumulate) {
+        V8<T>::load(cp, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      }
+      V8<T>::store(cp, v);
+    }
+    return;
+  }
   const long total = MN * Z;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int z = (int)(idx / MN);
@@ -466,8 +511,8 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     a.splitk = gemm_pick_splitk_dma(a, dt);
     if (int r = launch_gemm_dma(a, dt, st)) return r;
     if (a.splitk > 1) {
-      long total = (long)a.M * a.N * Z;
-      unsigned g = (unsigned)std::min<long>((total + 255) / 256, 4096);
+      long total = (long)a.M * a.N * Z / 4;
+      unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
       hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
       DPB_CHECK(hipGetLastError());
     }
@@ -483,8 +528,8 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 4>), grid, dim3(256), 0, st, a);
   }
   if (a.splitk > 1) {
-    long total = (long)a.M * a.N * Z;
-    unsigned g = (unsigned)std::min<long>((total + 255) / 256, 4096);
+    long total = (long)a.M * a.N * Z / 4;
+    unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
   }
   DPB_CHECK(hipGetLastError());
