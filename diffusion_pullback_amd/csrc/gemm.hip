@@ -431,6 +431,8 @@ int gemm_uses_big_tile(const GemmArgs& a) {
 int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (dtype != DT_BF16 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
   if (g_force_tile == 129) return 128;
+  if (g_force_tile == 131) return 130;
+  if (g_force_tile == 133) return 132;
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
@@ -439,8 +441,9 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
   // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
-  if (t128 >= 400) return 128;                  // chip filled by 128x128 tiles
-  if (a.K >= 2048 && t128 >= 64) return 128;    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
+  // (3-stage ring = 48 KiB -> 3 blocks/CU measured slightly ahead of 4 stages / 2 blocks and 2 stages / 5 blocks)
+  if (t128 >= 400) return 130;                  // chip filled by 128x128 tiles
+  if (a.K >= 2048 && t128 >= 64) return 130;    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
   if (t64 >= 256) return 64;
   return 0;
 }
@@ -448,7 +451,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = tile == 128 ? 128 : 64;
+  const int T = (tile == 128 || tile == 130 || tile == 132) ? 128 : 64;
   const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;

@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;     // 8 KiB + 8 KiB
   constexpr int P = S - 1;                                             // K-steps in flight
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, SLD = WN + 4;
-  __shared__ __attribute__((aligned(16))) char smem[S * STAGE];
-  static_assert(S * STAGE >= 4 * 32 * SLD * 4, "epilogue staging must fit in the ring");
+  constexpr int SMEM_BYTES = S * STAGE > 4 * 32 * SLD * 4 ? S * STAGE : 4 * 32 * SLD * 4;   // ring, reused by the epilogue staging
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,6 +287,12 @@ int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st) {
   if (tile == 128) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
     hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4>), grid, dim3(256), 0, st, a);
+  } else if (tile == 130) {       // 128x128 tile, 3-stage ring (48 KiB -> 3 blocks/CU)
+    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
+    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 3>), grid, dim3(256), 0, st, a);
+  } else if (tile == 132) {       // 128x128 tile, 2-stage ring (32 KiB -> 5 blocks/CU)
+    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
+    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 2>), grid, dim3(256), 0, st, a);
   } else if (tile == 64) {
     dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, sk);
     hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 4>), grid, dim3(256), 0, st, a);
