@@ -31,7 +31,8 @@ template <int D> struct FA {
   static constexpr int DO = ND * 32;
   static constexpr int BI = 64;                 // inner rows per LDS stage
   static constexpr int LDR = DP + 8;            // LDS stride of [row][d] tiles   (bf16 elements)
-  static constexpr int LDT = BI + 8;            // LDS stride of [d][row] tiles
+  static constexpr int LDT = BI + 4;            // LDS stride of [d][row] tiles: 68 elements = 34 dwords = 2*odd, so the 32 rows of a
+                                                // ds_read_b64 fragment read hit 32 distinct even banks (72 gave a 2-way conflict)
   static constexpr int ROW_ELEMS = BI * LDR;
   static constexpr int T_ELEMS = DO * LDT;
 };
@@ -83,7 +84,11 @@ __device__ inline void commit_t(const TRegs<D>& rg, bf16* lds, int tid) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int c = tid + i * 256;
-    if (c < F::DO * CPR) *reinterpret_cast<uint4*>(lds + (c / CPR) * F::LDT + (c % CPR) * 8) = rg.v[i];
+    if (c < F::DO * CPR) {                      // rows are 8-byte (not 16-byte) aligned: two ds_write_b64
+      bf16* dst = lds + (c / CPR) * F::LDT + (c % CPR) * 8;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(rg.v[i].x, rg.v[i].y);
+      *reinterpret_cast<uint2*>(dst + 4) = make_uint2(rg.v[i].z, rg.v[i].w);
+    }
   }
 }
 // B-operand fragments of 32 outer rows (row = lane&31), zero beyond D
