@@ -134,6 +134,94 @@ struct FusedArgs {
   float scale;
 };
 
+// ------------------------------------------------------------------------------------------------ primal (flash forward)
+// O = softmax(scale Q K^T) V with online softmax; also emits the row statistics (m, 1/l) the tangent / adjoint
+// kernels need, so the L x L probabilities are never materialised for the fused layers.  Same tiling as below:
+// lane <-> query, so the running max / sum and the rescale of the accumulator are register-local.
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
+  using F = FA<D>;
+  __shared__ __attribute__((aligned(16))) bf16 sm[F::ROW_ELEMS + F::T_ELEMS];
+  bf16* sK = sm; bf16* sVT = sK + F::ROW_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const long LC = (long)a.L * a.C;
+  const bf16* Kp = a.K + b * LC + h * D;
+  const bf16* VTp = a.VT + ((long)b * a.H + h) * D * a.L;
+  bf16x8 qf[F::NS];
+  load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
+  const float c2 = a.scale * 1.44269504088896f;          // scores in log2 units
+  f32x16 acc[F::ND];
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  RowRegs<D> rK;
+  TRegs<D> rVT;
+  fetch_row<D>(Kp, a.C, rK, tid); fetch_t<D>(VTp, a.L, rVT, tid);
+  for (int k0 = 0; k0 < a.L; k0 += F::BI) {
+    __syncthreads();
+    commit_row<D>(rK, sK, tid); commit_t<D>(rVT, sVT, tid);
+    __syncthreads();
+    if (k0 + F::BI < a.L) {
+      const int k1 = k0 + F::BI;
+      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_t<D>(VTp + k1, a.L, rVT, tid);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int stp = 0; stp < F::NS; ++stp) s = MFMA(lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), qf[stp], s);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] *= c2; mx = fmaxf(mx, s[r]); }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the other 16 keys of this query live in lane ^ 32
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float p[16], ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] - mn); ps += p[r]; }
+      ps += __shfl_xor(ps, 32, 64);
+      l = l * alpha + ps;
+      m = mn;
+#pragma unroll
+      for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+      bf16x8 pb[2];
+      pack_b(p, pb);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int d = 0; d < F::ND; ++d)
+          acc[d] = MFMA(lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi), pb[ks], acc[d]);
+    }
+  }
+  const float il = 1.f / l;
+  if (lhi == 0) {
+    float* st = stats_out + (((long)b * a.H + h) * a.L + q) * 2;
+    st[0] = m * 0.69314718055994531f;                     // natural-log units: max of the scaled scores
+    st[1] = il;
+  }
+  bf16* Op = O + b * (long)a.L * a.Co + (long)q * a.Co + h * D;
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = d * 32 + 8 * g + 4 * lhi;
+      if (col < D) {
+        bf16x8 tmp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tmp[i] = (__bf16)(acc[d][g * 4 + i] * il);
+        *reinterpret_cast<uint2*>(Op + col) = *reinterpret_cast<uint2*>(&tmp);
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ tangent
 template <int D>
 __global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
@@ -485,6 +573,16 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
   a.accQ = f.accQ; a.accK = f.accK; a.accV = f.accV;
   a.L = f.L; a.C = f.C; a.Co = f.Co; a.H = f.H; a.kps = f.kps; a.scale = f.scale;
   return a;
+}
+
+int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st) {
+  FusedArgs a = to_args(f);
+  dim3 grid(f.L / 128, batch * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, dim3(256), 0, st, a, (bf16*)O, stats);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, dim3(256), 0, st, a, (bf16*)O, stats);
+  else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  DPB_CHECK(hipGetLastError());
+  return 0;
 }
 
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {

@@ -348,6 +348,8 @@ static AttnPtrs attn_ptrs(dpb_engine* e, const dpb_op_desc& d, const AttnPlan& p
   return a;
 }
 
+static void fill_fused(dpb_engine* e, const AttnPlan& p, const AttnPtrs& x, FusedAttnArgs& f, int kps, float scale);
+
 int attn_primal(dpb_engine* e, const Op& op, int B) {
   const dpb_op_desc& d = op.d;
   const AttnPlan& p = e->plans[op.attn];
@@ -355,6 +357,16 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
   const float scale = 1.f / sqrtf((float)p.d);
   char* ws = e->ws;
   const AttnPtrs x = attn_ptrs(e, d, p, 0);
+  if (p.fused) {   // flash forward: O and the row statistics, no L x L object; keep the per-head transposes for the tangent/adjoint kernels
+    e->n_launch += 4;
+    if (int r = launch_transpose(e->dtype, x.V, ws + p.VT, B, H, (long)p.Lk * x.ldv, p.d, p.Lk, p.d, x.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    if (int r = launch_transpose(e->dtype, x.Q, ws + p.QT, B, H, (long)p.Lq * x.ldq, p.d, p.Lq, p.d, x.ldq, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+    FusedAttnArgs f;
+    fill_fused(e, p, x, f, 1, scale);
+    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * B * H;
+    return launch_attn_fwd_fused(f, B, x.O, (float*)(ws + p.stats), e->stream);
+  }
   GemmArgs g;   // S = scale * Q K^T
   g.A = x.Q; g.lda = x.ldq; g.sA1 = (long)p.Lq * x.ldq; g.sA2 = p.d;
   g.B = x.K; g.ldb = x.ldk; g.sB1 = (long)p.Lk * x.ldk; g.sB2 = p.d;
@@ -632,19 +644,20 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
     if (d.kind == DPB_OP_ATTENTION) {
       AttnPlan& p = e->plans[op.attn];
       const size_t H = p.heads;
-      p.P = take((size_t)e->maxB * H * p.Lq * p.Lkp * es);
-      p.VT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
-      p.KT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
-      s1 = std::max(s1, (size_t)e->maxT * H * p.Lq * p.Lkp * es);
-      size_t lmax = std::max(p.Lqp, p.Lkp);
-      t1 = std::max(t1, (size_t)e->maxT * H * p.d * lmax * es);
+      // long bf16 self-attention layers run the flash-style kernels (attn_fused.hip): no L x L object is ever stored
       p.fused = fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN") &&
                 e->bufs[d.in0].C == e->bufs[d.in1].C && e->bufs[d.in0].C == e->bufs[d.in2].C;
+      if (!p.fused) p.P = take((size_t)e->maxB * H * p.Lq * p.Lkp * es);
+      p.VT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
+      p.KT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
+      if (!p.fused) s1 = std::max(s1, (size_t)e->maxT * H * p.Lq * p.Lkp * es);
+      size_t lmax = std::max(p.Lqp, p.Lkp);
+      t1 = std::max(t1, (size_t)e->maxT * H * p.d * lmax * es);
       if (p.fused) p.stats = take((size_t)e->maxB * H * p.Lq * 2 * sizeof(float));
       if (!p.kv_const) {
-        p.PT = take((size_t)e->maxB * H * p.Lk * p.Lqp * es);
+        if (!p.fused) p.PT = take((size_t)e->maxB * H * p.Lk * p.Lqp * es);
         p.QT = take((size_t)e->maxB * H * p.d * p.Lqp * es);
-        s2 = std::max(s2, (size_t)e->maxT * H * p.Lk * p.Lqp * es);
+        if (!p.fused) s2 = std::max(s2, (size_t)e->maxT * H * p.Lk * p.Lqp * es);
         dv = std::max(dv, (size_t)e->maxT * H * p.Lq * sizeof(float));
       }
     } else if (d.kind == DPB_OP_GROUPNORM) {

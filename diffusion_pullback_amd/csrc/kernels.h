@@ -94,6 +94,7 @@ struct FusedAttnArgs {
 };
 int fused_attention_supported(int dtype, int d, int L, int kv_const);
 int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st);
+int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st);   // primal O + row statistics
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st);
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st);
 
