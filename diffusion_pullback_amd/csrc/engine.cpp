@@ -680,7 +680,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   const size_t nio = (size_t)std::max(e->maxB, e->maxT) * maxrc * sizeof(float);
   e->io_in = take(nio);
   e->io_out = take(nio);
-  e->orth = take(sizeof(double) * (3 * 16 * 16 + 2) * (size_t)e->maxB);
+  e->orth = take(sizeof(double) * (3 * 56 * 56 + 2) * (size_t)e->maxB);
   e->slab = take(e->slab_bytes);
   e->zeros = take(256);
   const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
@@ -811,7 +811,7 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
 
 int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, float* conv, int k, int n_iters) {
   if (!e || !V || !U || !s || !conv) return fail("null argument");
-  if (k < 1 || k > 16) return fail("pca_rank k=%d outside [1,16]", k);
+  if (k < 1 || k > 56) return fail("pca_rank k=%d outside [1,56]", k);
   const int B = e->cur_batch;                       // samples advanced together: one weight stream for all of them
   if (int r = check_tap(e, tap, k * (B > 0 ? B : 1))) return r;
   const int nt = k * B;
@@ -826,7 +826,7 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
     for (int b = 0; b < B; ++b)                     // independent k x N re-orthonormalisation per sample
       if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, Vn + (long)b * k * N, s + b * k, conv + 2 * b,
-                           e->ws + e->orth + (size_t)b * sizeof(double) * (3 * 16 * 16 + 2), k, N, e->stream)) return r;
+                           e->ws + e->orth + (size_t)b * sizeof(double) * (3 * 56 * 56 + 2), k, N, e->stream)) return r;
     DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * nt * N, hipMemcpyDeviceToDevice, e->stream));
     launches += 5 * B + 1;
   }

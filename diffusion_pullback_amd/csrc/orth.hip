@@ -14,11 +14,12 @@
 
 namespace dpb {
 
-constexpr int KMAX = 16;
+constexpr int KMAX_ALL = 56;          // largest supported rank (the reference's default pca_rank is 50)
 
-// grid (nblk, k): block row i accumulates G[i][:] and X[i][:] = W_i . Vprev_j over a slice of N
+// grid (nblk, k, ceil(k/16)): block (i, jt) accumulates G[i][jt*16..] and X[i][jt*16..] = W_i . Vprev_j over a slice of N
 __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* Vp, double* G, double* X, int k, long N) {
-  const int i = blockIdx.y;
+  constexpr int KMAX = 16;
+  const int i = blockIdx.y, j0 = blockIdx.z * KMAX;
   double g[KMAX], x[KMAX];   // fp64 accumulation: small singular values survive the squaring in the Gram matrix
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) g[j] = x[j] = 0.0;
@@ -26,9 +27,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* 
     const double wi = W[(long)i * N + n];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
-      if (j < k) {
-        g[j] += wi * (double)W[(long)j * N + n];
-        x[j] += wi * (double)Vp[(long)j * N + n];
+      if (j0 + j < k) {
+        g[j] += wi * (double)W[(long)(j0 + j) * N + n];
+        x[j] += wi * (double)Vp[(long)(j0 + j) * N + n];
       }
     }
   }
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
-    if (j < k) {
+    if (j0 + j < k) {
       double a = g[j], b = x[j];
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
       if (lane == 0) { red[0][j][wave] = a; red[1][j][wave] = b; }
@@ -45,15 +46,16 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* 
   __syncthreads();
   if (threadIdx.x < 2 * KMAX) {
     int w = threadIdx.x / KMAX, j = threadIdx.x % KMAX;
-    if (j < k) {
+    if (j0 + j < k) {
       double s = red[w][j][0] + red[w][j][1] + red[w][j][2] + red[w][j][3];
-      atomicAdd((w == 0 ? G : X) + i * k + j, s);
+      atomicAdd((w == 0 ? G : X) + i * k + j0 + j, s);
     }
   }
 }
 
 // one wave: parallel cyclic Jacobi eigen-solve of the symmetric k x k Gram matrix (thread r owns row/col r),
 // then the mixing matrix Cm with V_i = sum_j Cm[i][j] W_j.
+template <int KMAX>
 __global__ __launch_bounds__(64) void eig_kernel(const double* G, const double* X, double* Cm, float* s_out, int k) {
   __shared__ double A[KMAX][KMAX + 1], Q[KMAX][KMAX + 1];
   __shared__ int order[KMAX];
@@ -64,7 +66,12 @@ __global__ __launch_bounds__(64) void eig_kernel(const double* G, const double* 
       Q[r][j] = r == j ? 1.0 : 0.0;
     }
   __syncthreads();
-  for (int sweep = 0; sweep < 12; ++sweep) {
+  for (int sweep = 0; sweep < 14; ++sweep) {
+    // converged when the off-diagonal mass is negligible (checked by every thread on the same data: uniform)
+    double off = 0, diag = 0;
+    for (int i = 0; i < k; ++i) { diag += A[i][i] * A[i][i]; for (int j = i + 1; j < k; ++j) off += A[i][j] * A[i][j]; }
+    __syncthreads();
+    if (off <= 1e-28 * diag) break;
     for (int p = 0; p < k - 1; ++p)
       for (int q = p + 1; q < k; ++q) {
         const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(64) void eig_kernel(const double* G, const double* 
   }
 }
 
+template <int KMAX>
 __global__ __launch_bounds__(256) void orth_apply_kernel(const float* W, const float* Vp, float* V, const double* Cm, double* acc, int k,
                                                          long N) {
   __shared__ double cm[KMAX * KMAX];
@@ -159,7 +167,7 @@ __global__ void orth_finish_kernel(const double* acc, float* conv) {
 }
 
 int launch_orth(const OrthArgs& a, hipStream_t st) {
-  if (a.k < 1 || a.k > KMAX) { set_error("orth: pca_rank k=%d outside [1,%d]", a.k, KMAX); return -1; }
+  if (a.k < 1 || a.k > KMAX_ALL) { set_error("orth: pca_rank k=%d outside [1,%d]", a.k, KMAX_ALL); return -1; }
   const int k = a.k;
   double* G = a.scratch;
   double* X = G + k * k;
@@ -168,9 +176,14 @@ int launch_orth(const OrthArgs& a, hipStream_t st) {
   DPB_CHECK(hipMemsetAsync(a.scratch, 0, sizeof(double) * (3 * k * k + 2), st));
   unsigned nb = (unsigned)((a.N + 2047) / 2048);
   if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(gram_kernel, dim3(nb, k), dim3(256), 0, st, a.W, a.Vprev, G, X, k, a.N);
-  hipLaunchKernelGGL(eig_kernel, dim3(1), dim3(64), 0, st, G, X, Cm, a.s, k);
-  hipLaunchKernelGGL(orth_apply_kernel, dim3(nb), dim3(256), 0, st, a.W, a.Vprev, a.V, Cm, acc, k, a.N);
+  hipLaunchKernelGGL(gram_kernel, dim3(nb, k, (k + 15) / 16), dim3(256), 0, st, a.W, a.Vprev, G, X, k, a.N);
+  if (k <= 16) {
+    hipLaunchKernelGGL((eig_kernel<16>), dim3(1), dim3(64), 0, st, G, X, Cm, a.s, k);
+    hipLaunchKernelGGL((orth_apply_kernel<16>), dim3(nb), dim3(256), 0, st, a.W, a.Vprev, a.V, Cm, acc, k, a.N);
+  } else {
+    hipLaunchKernelGGL((eig_kernel<KMAX_ALL>), dim3(1), dim3(64), 0, st, G, X, Cm, a.s, k);
+    hipLaunchKernelGGL((orth_apply_kernel<KMAX_ALL>), dim3(nb), dim3(256), 0, st, a.W, a.Vprev, a.V, Cm, acc, k, a.N);
+  }
   hipLaunchKernelGGL(orth_finish_kernel, dim3(1), dim3(1), 0, st, acc, a.conv);
   DPB_CHECK(hipGetLastError());
   return 0;

@@ -110,7 +110,7 @@ int dpb_jvp(dpb_engine* e, int tap_buf, const float* V, int nt, float* U);
 /* W = J^T U : adjoint pass wrt the input only.  Replaces: autograd.functional.jacobian, utils.py:790-797. */
 int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
 
-/* Thin SVD of W [k][N] (fp32): V rows = right singular vectors (descending), s = sqrt(singular values),
+/* Thin SVD of W [k][N] (fp32, k <= 56): V rows = right singular vectors (descending), s = sqrt(singular values),
  * conv[0] = ||V - Vprev||_2, conv[1] = max(|V - Vprev| - 1e-5|V|).  scratch: >= 8*(3*k*k+2) bytes.
  * Replaces: torch.linalg.svd + dist/allclose inputs, utils.py:799-806.  Engine-independent. */
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
@@ -119,7 +119,7 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
 /* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev, for all B samples
  * of the last dpb_primal together (independent bases, one shared weight stream; B*k <= max_tangents).
  * V [B][k][N_in] in/out, U [B][k][N_h] out, s [B][k] out, conv [B][2] out (of the last iteration).
- * Replaces: the loop body utils.py:756-808 (k <= 16), once per sample of the batch. */
+ * Replaces: the loop body utils.py:756-808 (k <= 56), once per sample of the batch. */
 int dpb_pullback_iterate(dpb_engine* e, int tap_buf, float* V, float* U, float* s, float* conv, int k, int n_iters);
 
 /* DDIM update (utils.py:301-306 / :1220-1225, eta = 0) and the x-space-guidance axpy (edit.py:490, :501). */

@@ -115,7 +115,7 @@ def test_orth_matches_svd():
     from diffusion_pullback_amd import lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(4)
-    for k, n in [(1, 64), (3, 1000), (5, 16384), (10, 196608), (16, 4099)]:
+    for k, n in [(1, 64), (3, 1000), (5, 16384), (10, 196608), (16, 4099), (17, 3000), (50, 16384)]:
         scale = torch.logspace(0, -2, k)[:, None]
         W = (torch.randn(k, k, generator=g) @ (scale * torch.linalg.qr(torch.randn(n, k, generator=g))[0].T)).float()
         Vp = torch.linalg.qr(torch.randn(n, k, generator=g))[0].T.contiguous().float()
