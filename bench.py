@@ -211,8 +211,9 @@ def main():
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
 
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 
