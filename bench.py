@@ -46,7 +46,7 @@ def parse():
                     help="x_t samples advanced together per GPU (independent bases, shared weight stream); steps must be a multiple")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-k", type=int, default=1, help="directions in the bounded CPU sample (scaled to k; 0 = all k)")
+    ap.add_argument("--cpu-k", type=int, default=0, help="directions in the bounded CPU sample (0 = all k: one full power iteration, ~20 s)")
     return ap.parse_args()
 
 
