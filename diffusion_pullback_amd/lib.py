@@ -83,6 +83,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import fcntl                     # fresh checkout: compile the HIP library in-tree (never a CPU substitute);
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:      # one builder when several ranks start together
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if not os.path.exists(LIB_PATH):
+                build()
+            fcntl.flock(lk, fcntl.LOCK_UN)
     if not os.path.exists(LIB_PATH):
         raise DpbError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the product path)")
