@@ -433,6 +433,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (g_force_tile == 129) return 128;
   if (g_force_tile == 131) return 130;
   if (g_force_tile == 133) return 132;
+  if (g_force_tile == 257) return 256;
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
@@ -451,8 +452,9 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = (tile == 128 || tile == 130 || tile == 132) ? 128 : 64;
-  const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
+  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256) ? 128 : 64;
+  const int TMm = tile == 256 ? 256 : T;
+  const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;
   if (g_force_splitk) s = g_force_splitk;

@@ -29,7 +29,7 @@ __device__ inline bf16x8 lds_read_b128(unsigned addr) {
   return v;
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int GATHER>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   constexpr int BK = 32, CH = 8;
   constexpr int NIA = BM / 64, NIB = BN / 64;                          // DMA wave-instructions per stage per wave (A, B)
@@ -63,80 +63,94 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
     kt_begin = blockIdx.z * per;
     nk = max(0, min(nk_all, kt_begin + per) - kt_begin);
   }
-  // ---- DMA slots of this lane: wave instruction i covers LDS chunks (wave*2+i)*64 + lane of the A (B) tile
-  // (A and B tiles have the same height here, so one slot index serves both)
-  static_assert(BM == BN, "square tiles only");
-  constexpr int NI = NIA;
-  const bf16* a_base[NI];
-  const bf16* b_base[NI];
-  int a_oy[NI], a_ox[NI], kc[NI], tap[NI], cc[NI];
-  bool a_ok[NI], b_ok[NI];
+  // ---- DMA slots of this lane: wave instruction i covers LDS chunks (wave*NI+i)*64 + lane of the A (resp. B) tile.
+  // A slot = one 16-byte chunk (row, physical chunk column); its logical K chunk is swizzled on the source side.
+  // The gather (GATHER is a compile-time mode) is resolved once per filter tap, not once per K-step: a_cur[i] is the
+  // source pixel's channel vector for the current tap (nullptr = padding), so the steady state is one add per slot.
+  const int K = p.K, Cin = p.Cin, Wd = p.W, Hd = p.H, lda = p.lda, strd = p.stride, pad = p.pad, KS = p.KS;
+  const bf16* a_base[NIA];
+  const bf16* a_cur[NIA];
+  int a_oy[NIA], a_ox[NIA], kca[NIA], tap[NIA], cc[NIA];
+  auto retap = [&](int i) {
+    if constexpr (GATHER == GATHER_NONE) {
+      a_cur[i] = a_base[i];
+    } else {
+      int ky = 0, kx = 0;
+      if (KS == 3) { ky = (tap[i] * 11) >> 5; kx = tap[i] - ky * 3; }
+      int iy, ix;
+      bool ok = a_base[i] != nullptr;
+      if constexpr (GATHER == GATHER_CONV) {
+        iy = a_oy[i] * strd + ky - pad;
+        ix = a_ox[i] * strd + kx - pad;
+        ok = ok && iy >= 0 && iy < Hd && ix >= 0 && ix < Wd;
+      } else if constexpr (GATHER == GATHER_CONVT) {
+        int ty = a_oy[i] + pad - ky, tx = a_ox[i] + pad - kx;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (strd == 2) { ok = ok && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; } else { iy = ty; ix = tx; }
+        ok = ok && iy < Hd && ix < Wd;
+      } else {
+        int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
+        ok = ok && uy >= 0 && ux >= 0 && uy < 2 * Hd && ux < 2 * Wd;
+        iy = uy >> 1; ix = ux >> 1;
+      }
+      a_cur[i] = ok ? a_base[i] + ((long)iy * Wd + ix) * lda : nullptr;
+    }
+  };
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int pos = (wave * NI + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
+  for (int i = 0; i < NIA; ++i) {
+    const int pos = (wave * NIA + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
     const int kq = phys ^ ((row >> 2) & 3);
-    kc[i] = kt_begin * BK + kq * CH;
-    const int m = m0 + row, n = n0 + row;
-    a_ok[i] = m < p.M;
-    b_ok[i] = n < p.N;
-    b_base[i] = B + (long)n * p.ldb;
+    kca[i] = kt_begin * BK + kq * CH;
+    const int m = m0 + row;
     a_oy[i] = a_ox[i] = 0;
     tap[i] = 0;
-    cc[i] = kc[i];
-    if (p.gather == GATHER_NONE) {
-      a_base[i] = A + (long)m * p.lda;
+    cc[i] = kca[i];
+    if constexpr (GATHER == GATHER_NONE) {
+      a_base[i] = m < p.M ? A + (long)m * lda : nullptr;
     } else {
       const int hw = p.Ho * p.Wo, smp = m / hw, rem = m - smp * hw;
       a_oy[i] = rem / p.Wo;
       a_ox[i] = rem - a_oy[i] * p.Wo;
-      a_base[i] = A + (long)smp * p.H * p.W * p.lda;
-      tap[i] = kc[i] / p.Cin;
-      cc[i] = kc[i] - tap[i] * p.Cin;
+      a_base[i] = m < p.M ? A + (long)smp * Hd * Wd * lda : nullptr;
+      tap[i] = kca[i] / Cin;
+      cc[i] = kca[i] - tap[i] * Cin;
     }
+    retap(i);
+  }
+  const bf16* b_base[NIB];
+  int kcb[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int pos = (wave * NIB + i) * 64 + lane, row = pos >> 2, phys = pos & 3;
+    kcb[i] = kt_begin * BK + (phys ^ ((row >> 2) & 3)) * CH;
+    const int n = n0 + row;
+    b_base[i] = n < p.N ? B + (long)n * p.ldb : nullptr;
   }
   auto issue = [&](int slot) {
     char* st = smem + slot * STAGE;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const bf16* src = zero;
-      bool ok = a_ok[i] && kc[i] < p.K;
-      if (p.gather == GATHER_NONE) {
-        if (ok) src = a_base[i] + kc[i];
-      } else {
-        int ky = 0, kx = 0;
-        if (p.KS == 3) { ky = (tap[i] * 11) >> 5; kx = tap[i] - ky * 3; }
-        int iy, ix;
-        if (p.gather == GATHER_CONV) {
-          iy = a_oy[i] * p.stride + ky - p.pad;
-          ix = a_ox[i] * p.stride + kx - p.pad;
-          ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        } else if (p.gather == GATHER_CONVT) {
-          int ty = a_oy[i] + p.pad - ky, tx = a_ox[i] + p.pad - kx;
-          ok = ok && ty >= 0 && tx >= 0;
-          if (p.stride == 2) { ok = ok && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; } else { iy = ty; ix = tx; }
-          ok = ok && iy < p.H && ix < p.W;
-        } else {
-          int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
-          ok = ok && uy >= 0 && ux >= 0 && uy < 2 * p.H && ux < 2 * p.W;
-          iy = uy >> 1; ix = ux >> 1;
+    for (int i = 0; i < NIA; ++i) {
+      const bf16* src = (a_cur[i] && kca[i] < K) ? a_cur[i] + cc[i] : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * NIA + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const bf16* src = (b_base[i] && kcb[i] < K) ? b_base[i] + kcb[i] : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + A_BYTES + (wave * NIB + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      kca[i] += BK;
+      cc[i] += BK;
+      if constexpr (GATHER != GATHER_NONE) {
+        if (cc[i] >= Cin) {                        // next filter tap (every Cin/32 steps; uniform when Cin % 32 == 0)
+          do { cc[i] -= Cin; ++tap[i]; } while (cc[i] >= Cin);
+          retap(i);
         }
-        if (ok) src = a_base[i] + ((long)iy * p.W + ix) * p.lda + cc[i];
-      }
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * NI + i) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const bf16* src = (b_ok[i] && kc[i] < p.K) ? b_base[i] + kc[i] : zero;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + A_BYTES + (wave * NI + i) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      kc[i] += BK;
-      if (p.gather != GATHER_NONE) {
-        cc[i] += BK;
-        while (cc[i] >= p.Cin) { cc[i] -= p.Cin; ++tap[i]; }
       }
     }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) kcb[i] += BK;
   };
 
   f32x16 acc[TM][TN];
@@ -169,22 +183,25 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt landed for this wave: everything issued after it may still be in flight (4 DMA instructions per stage)
     const int later = min(P - 1, nk - 1 - kt);     // stages issued after stage kt that may still be in flight
-    if constexpr (NI == 2) {                       // 4 DMA instructions per stage
-      if (later >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (later == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {                                       // 2 DMA instructions per stage
-      if (later >= 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (later == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (later == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    constexpr int U = NIA + NIB;                   // DMA instructions per stage per wave
+    static_assert(P - 1 <= 3, "add vmcnt cases for a deeper ring");
+    if constexpr (U == 2) {
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (U == 4) {
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      static_assert(U == 6, "unsupported tile shape");
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    static_assert(P - 1 <= (NI == 2 ? 4 : 6), "add vmcnt cases for a deeper ring");
     __builtin_amdgcn_s_barrier();          // ... and for every other wave; also: stage kt-1 is fully consumed
     if (kt + P < nk) issue((kt + P) % S);  // refill the slot stage kt-1 occupied
     const unsigned sb = lds0 + (kt % S) * STAGE;
@@ -282,24 +299,25 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   }
 }
 
+template <int BM, int BN, int S>
+static void launch_dma_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.gather) {
+    case GATHER_NONE: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE>), grid, dim3(256), 0, st, a); break;
+    case GATHER_CONV: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONV>), grid, dim3(256), 0, st, a); break;
+    case GATHER_CONVT: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONVT>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_UPCONV>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
-  if (tile == 128) {
-    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
-    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4>), grid, dim3(256), 0, st, a);
-  } else if (tile == 130) {       // 128x128 tile, 3-stage ring (48 KiB -> 3 blocks/CU)
-    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
-    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 3>), grid, dim3(256), 0, st, a);
-  } else if (tile == 132) {       // 128x128 tile, 2-stage ring (32 KiB -> 5 blocks/CU)
-    dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), a.Z1 * a.Z2, sk);
-    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 2>), grid, dim3(256), 0, st, a);
-  } else if (tile == 64) {
-    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, sk);
-    hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 4>), grid, dim3(256), 0, st, a);
-  } else {
-    dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), a.Z1 * a.Z2, sk);
-    hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 6>), grid, dim3(256), 0, st, a);
-  }
+  const int Z = a.Z1 * a.Z2;
+  auto tiles = [&](int bm, int bn) { return dim3(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn), Z, sk); };
+  if (tile == 128) launch_dma_t<128, 128, 4>(a, tiles(128, 128), st);
+  else if (tile == 130) launch_dma_t<128, 128, 3>(a, tiles(128, 128), st);        // 48 KiB ring -> 3 blocks/CU (default)
+  else if (tile == 256) launch_dma_t<256, 128, 3>(a, tiles(256, 128), st);        // wave tile 128x64, 72 KiB ring
+  else if (tile == 132) launch_dma_t<128, 128, 2>(a, tiles(128, 128), st);
+  else launch_dma_t<64, 64, 4>(a, tiles(64, 64), st);
   DPB_CHECK(hipGetLastError());
   return 0;
 }

@@ -197,7 +197,7 @@ def test_dma_gemm_bitwise_equals_register_gemm():
                 L.check(lib.dpb_debug_set(b"gemm_tile", 64)); L.check(lib.dpb_debug_set(b"gemm_splitk", sk))
                 ref = run()
                 assert all(torch.isfinite(r).all() for r in ref)
-                for code in (129, 65, 67):                      # 128x128 ring, 64x64 ring (4 and 6 stages)
+                for code in (129, 131, 65, 257):                # 128x128 ring (4 / 3 stages), 64x64 ring, 256x128 ring
                     L.check(lib.dpb_debug_set(b"gemm_tile", code))
                     for rep in range(3):
                         got = run()
