@@ -39,7 +39,7 @@ template <> struct V8<bf16> {
   __device__ static inline void store(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
 };
 
-template <typename T, int BM, int BN, int KCH>
+template <typename T, int BM, int BN, int KCH, int GATHER>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int CH = TT<T>::CH;
   constexpr int BK = KCH * CH;           // K elements per step (KCH 16-byte chunks per row)
@@ -77,36 +77,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const T* R = p.R ? (const T*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 : nullptr;
 
   const int kq = tid % KCH, r0 = tid / KCH;
-  // ---- per-thread A rows
+  // ---- per-thread A rows.  GATHER is a compile-time mode; the gathered pixel is resolved once per filter tap
+  // (a_cur[i] = channel vector of the source pixel, nullptr = padding), so a K-step costs one add per chunk.
+  const int K = p.K, Cin = p.Cin, Wd = p.W, Hd = p.H, lda = p.lda, strd = p.stride, pad = p.pad, KS = p.KS;
   const T* a_base[NA];
+  const T* a_cur[NA];
   int a_oy[NA], a_ox[NA];
-  bool a_ok[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int row = r0 + i * RPP;
     int m = m0 + row;
-    a_ok[i] = m < p.M;
     a_oy[i] = a_ox[i] = 0;
-    if (p.gather == GATHER_NONE) {
-      a_base[i] = A + (long)m * p.lda;
+    if constexpr (GATHER == GATHER_NONE) {
+      a_base[i] = m < p.M ? A + (long)m * lda : nullptr;
     } else {
       int hw = p.Ho * p.Wo;
       int smp = m / hw, rem = m - smp * hw;
       a_oy[i] = rem / p.Wo;
       a_ox[i] = rem - a_oy[i] * p.Wo;
-      a_base[i] = A + (long)smp * p.H * p.W * p.lda;
+      a_base[i] = m < p.M ? A + (long)smp * Hd * Wd * lda : nullptr;
     }
   }
   const T* b_base[NB];
-  bool b_ok[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     int n = n0 + r0 + i * RPP;
-    b_ok[i] = n < p.N;
-    b_base[i] = B + (long)n * p.ldb;
+    b_base[i] = n < p.N ? B + (long)n * p.ldb : nullptr;
   }
   // K range of this block (split-K over blockIdx.z; steps of BK)
-  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk1 = (K + BK - 1) / BK;
   const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
   const int nk_all = nk1 + nk2;
   int kt0 = 0, kt1 = nk_all;
@@ -115,75 +114,73 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     kt0 = blockIdx.z * per;
     kt1 = min(nk_all, kt0 + per);
   }
-  // running (k, tap, channel) of this thread's chunk column
+  // running (k, tap, channel) of this thread's chunk column (all of a thread's chunks share the column)
   int kl = kt0;                       // next step to load
-  int klim = p.K;
+  int klim = K;
   int kc = kt0 * BK + kq * CH, tap = 0, cc = kc;
-  if (p.gather != GATHER_NONE) {
-    tap = kc / p.Cin;
-    cc = kc - tap * p.Cin;
+  if constexpr (GATHER != GATHER_NONE) {
+    tap = kc / Cin;
+    cc = kc - tap * Cin;
   }
+  auto retap = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if constexpr (GATHER == GATHER_NONE) {
+        a_cur[i] = a_base[i];
+      } else {
+        int ky = 0, kx = 0;
+        if (KS == 3) { ky = (tap * 11) >> 5; kx = tap - ky * 3; }
+        int iy, ix;
+        bool ok = a_base[i] != nullptr;
+        if constexpr (GATHER == GATHER_CONV) {
+          iy = a_oy[i] * strd + ky - pad;
+          ix = a_ox[i] * strd + kx - pad;
+          ok = ok && iy >= 0 && iy < Hd && ix >= 0 && ix < Wd;
+        } else if constexpr (GATHER == GATHER_CONVT) {
+          int ty = a_oy[i] + pad - ky, tx = a_ox[i] + pad - kx;
+          ok = ok && ty >= 0 && tx >= 0;
+          if (strd == 2) { ok = ok && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; } else { iy = ty; ix = tx; }
+          ok = ok && iy < Hd && ix < Wd;
+        } else {   // GATHER_UPCONV: nearest x2 then 3x3 pad 1
+          int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
+          ok = ok && uy >= 0 && ux >= 0 && uy < 2 * Hd && ux < 2 * Wd;
+          iy = uy >> 1; ix = ux >> 1;
+        }
+        a_cur[i] = ok ? a_base[i] + ((long)iy * Wd + ix) * lda : nullptr;
+      }
+    }
+  };
+  retap();
 
   uint4 ra[NA], rb[NB];
   auto gload = [&]() {
-    if (nk2 && kl == nk1) {           // switch to the second operand pair
+    if (nk2 && kl == nk1) {           // switch to the second operand pair (plain rows only)
       const T* A2 = (const T*)p.A2 + (long)(z1 / p.divA2) * p.sA21 + (long)z2 * p.sA22;
       const T* B2 = (const T*)p.B2 + (long)(z1 / p.divB2) * p.sB21 + (long)z2 * p.sB22;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) a_base[i] = A2 + (long)(m0 + r0 + i * RPP) * p.lda2;
+      for (int i = 0; i < NA; ++i) a_cur[i] = a_base[i] ? A2 + (long)(m0 + r0 + i * RPP) * p.lda2 : nullptr;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) b_base[i] = B2 + (long)(n0 + r0 + i * RPP) * p.ldb2;
+      for (int i = 0; i < NB; ++i) b_base[i] = b_base[i] ? B2 + (long)(n0 + r0 + i * RPP) * p.ldb2 : nullptr;
       kc = kq * CH;
+      cc = kc;
       klim = p.K2;
     }
     ++kl;
     const bool kok = kc < klim;
-    int ky = 0, kx = 0;
-    if (p.gather != GATHER_NONE && p.KS == 3) {
-      ky = (tap * 11) >> 5;
-      kx = tap - ky * 3;
-    }
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const T* ptr = nullptr;
-      bool ok = a_ok[i] && kok;
-      if (p.gather == GATHER_NONE) {
-        ptr = a_base[i] + kc;
-      } else {
-        int iy, ix;
-        if (p.gather == GATHER_CONV) {
-          iy = a_oy[i] * p.stride + ky - p.pad;
-          ix = a_ox[i] * p.stride + kx - p.pad;
-          ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        } else if (p.gather == GATHER_CONVT) {
-          int ty = a_oy[i] + p.pad - ky, tx = a_ox[i] + p.pad - kx;
-          ok = ok && ty >= 0 && tx >= 0;
-          if (p.stride == 2) {
-            ok = ok && !((ty | tx) & 1);
-            iy = ty >> 1; ix = tx >> 1;
-          } else {
-            iy = ty; ix = tx;
-          }
-          ok = ok && iy < p.H && ix < p.W;
-        } else {   // GATHER_UPCONV: nearest x2 then 3x3 pad 1
-          int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
-          ok = ok && uy >= 0 && ux >= 0 && uy < 2 * p.H && ux < 2 * p.W;
-          iy = uy >> 1; ix = ux >> 1;
-        }
-        ptr = a_base[i] + ((long)iy * p.W + ix) * p.lda + cc;
-      }
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(ptr) : make_uint4(0, 0, 0, 0);
-    }
+    for (int i = 0; i < NA; ++i)
+      ra[i] = (kok && a_cur[i]) ? *reinterpret_cast<const uint4*>(a_cur[i] + cc) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      bool ok = b_ok[i] && kok;
-      rb[i] = ok ? *reinterpret_cast<const uint4*>(b_base[i] + kc) : make_uint4(0, 0, 0, 0);
-    }
+    for (int i = 0; i < NB; ++i)
+      rb[i] = (kok && b_base[i]) ? *reinterpret_cast<const uint4*>(b_base[i] + kc) : make_uint4(0, 0, 0, 0);
     // advance to the next K step
     kc += BK;
-    if (p.gather != GATHER_NONE) {
-      cc += BK;
-      while (cc >= p.Cin) { cc -= p.Cin; ++tap; }
+    cc += BK;
+    if constexpr (GATHER != GATHER_NONE) {
+      if (cc >= Cin) {                  // next filter tap (every Cin/BK steps)
+        do { cc -= Cin; ++tap; } while (cc >= Cin);
+        retap();
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -419,12 +416,16 @@ static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0, g_dma_auto = 1;
 void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 
-int gemm_uses_big_tile(const GemmArgs& a) {
-  // Measured on MI355X (tests/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt): with this single-stage register
-  // prefetch the 64x64 tile (7 blocks/CU in flight) beats the 128x128 tile (latency-bound at <= 4 blocks/CU) on every
-  // layer shape of the path, so the big tile is only selectable explicitly until it gets a deeper pipeline.
-  (void)a;
-  return g_force_tile == 128;
+int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
+  // Register-staged kernel, measured on MI355X (tests/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt):
+  // bf16 -- the 64x64 tile (7 blocks/CU in flight) beats the 128x128 tile, which is latency-bound at <= 4 blocks/CU
+  //         (large bf16 problems go to the asynchronous ring kernels instead);
+  // fp32 -- the slow fp32 MFMA (64 cycles) hides the load latency: with >= 4 tiles per CU the 128x128 tile wins
+  //         (119 vs 93 TF/s on the 256x256-resolution DDPM convolutions), below that the 64x64 tile.
+  if (g_force_tile) return g_force_tile == 128;
+  if (dtype != DT_F32 || a.A2) return 0;
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
+  return t128 >= 1024;
 }
 
 // the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
@@ -444,7 +445,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (!g_dma_auto || a.K < 256) return 0;
   // (3-stage ring = 48 KiB -> 3 blocks/CU measured slightly ahead of 4 stages / 2 blocks and 2 stages / 5 blocks)
   if (t128 >= 400) return 130;                  // chip filled by 128x128 tiles
-  if (a.K >= 2048 && t128 >= 64) return 130;    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
+  if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
   if (t64 >= 256) return 64;
   return 0;
 }
@@ -479,7 +480,7 @@ int gemm_kch(const GemmArgs& a) {
 int gemm_pick_splitk(int dtype, const GemmArgs& a) {
   if (a.A2 || !a.slab) return 1;
   const int BK = (dtype == DT_F32 ? 4 : 8) * gemm_kch(a);
-  const int T = gemm_uses_big_tile(a) ? 128 : 64;
+  const int T = gemm_uses_big_tile(dtype, a) ? 128 : 64;
   const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + BK - 1) / BK;
   long s;
@@ -495,6 +496,16 @@ int gemm_pick_splitk(int dtype, const GemmArgs& a) {
   const long per = (long)a.M * a.N * a.Z1 * a.Z2 * 4;
   if (s * per > (long)a.slab_bytes) s = (long)a.slab_bytes / per;
   return (int)std::max<long>(s, 1);
+}
+
+template <typename T, int BM, int BN, int KCH>
+static void launch_reg_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.gather) {
+    case GATHER_NONE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KCH, GATHER_NONE>), grid, dim3(256), 0, st, a); break;
+    case GATHER_CONV: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KCH, GATHER_CONV>), grid, dim3(256), 0, st, a); break;
+    case GATHER_CONVT: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KCH, GATHER_CONVT>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, KCH, GATHER_UPCONV>), grid, dim3(256), 0, st, a); break;
+  }
 }
 
 template <typename T>
@@ -524,13 +535,13 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     return 0;
   }
   a.splitk = gemm_pick_splitk(dtype, a);
-  if (gemm_uses_big_tile(a)) {
+  if (gemm_uses_big_tile(dtype, a)) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 4>), grid, dim3(256), 0, st, a);
+    launch_reg_t<T, 128, 128, 4>(a, grid, st);
   } else {
     dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), Z, a.splitk);
-    if (gemm_kch(a) == 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 8>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 4>), grid, dim3(256), 0, st, a);
+    if (gemm_kch(a) == 8) launch_reg_t<T, 64, 64, 8>(a, grid, st);
+    else launch_reg_t<T, 64, 64, 4>(a, grid, st);
   }
   if (a.splitk > 1) {
     long total = (long)a.M * a.N * Z / 4;

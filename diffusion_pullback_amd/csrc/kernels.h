@@ -36,7 +36,7 @@ struct GemmArgs {
   int splitk = 1, vec_ok = 0;
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
-int gemm_uses_big_tile(const GemmArgs& a);
+int gemm_uses_big_tile(int dtype, const GemmArgs& a);
 void gemm_debug_set(int tile, int splitk, int kch);
 int gemm_kch(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st);   // bf16, single operand pair, no split-K (gemm_dma.hip); tile 128 | 64 | 66 (64 with a 6-stage ring)

@@ -21,7 +21,7 @@ def conv_engine(H, cin, cout, ks, dtype, batch):
     return Engine(t, 8, False, True, cin, max_batch=batch, max_tangents=batch)
 
 
-def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((0, 0, 4), (131, 1, 4), (257, 1, 4), (257, 0, 4))):
+def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((0, 0, 4), (64, 0, 4), (65, 0, 4))):
     e = conv_engine(H, cin, cout, ks, dtype, batch)
     x = torch.randn(batch, cin, H, H, device=DEV)
     M, N, K = batch * H * H, cout, ks * ks * cin
@@ -51,5 +51,5 @@ if __name__ == "__main__":
     run("lin 16^2 1280->1280 b5", 16, 1280, 1280, 1, 5)
     run("lin 64^2 320->2560 b5", 64, 320, 2560, 1, 5)
     run("lin 32^2 640->5120 b5", 32, 640, 5120, 1, 5)
-    run("conv3x3 256^2 128->128 f32 b5", 256, 128, 128, 3, 5, torch.float32, ((64, 0, 4), (64, 0, 8)))
-    run("conv3x3 64^2 256->256 f32 b5", 64, 256, 256, 3, 5, torch.float32, ((64, 0, 4), (64, 0, 8), (64, 2, 8)))
+    run("conv3x3 256^2 128->128 f32 b5", 256, 128, 128, 3, 5, torch.float32, ((64, 0, 4), (128, 1, 4)))
+    run("conv3x3 64^2 256->256 f32 b5", 64, 256, 256, 3, 5, torch.float32, ((64, 0, 4), (128, 1, 4)))
