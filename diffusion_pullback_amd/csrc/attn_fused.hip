@@ -24,6 +24,9 @@ namespace dpb {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+constexpr int ATT_WAVES = 8;                    // waves per block: 8 x 32 = 256 outer rows share every streamed tile
+constexpr int ATT_NT = ATT_WAVES * 64;
+
 template <int D> struct FA {
   static constexpr int NS = (D + 15) / 16;      // k-steps of the score products
   static constexpr int DP = NS * 16;            // padded head dim (score products)
@@ -40,14 +43,14 @@ template <int D> struct FA {
 // Register-staged tile loads: fetch() issues the global loads of the NEXT stage before the MFMAs of the current one,
 // commit() writes them to LDS after the barrier, so HBM/L2 latency overlaps the compute.
 // Row tile: [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled.
-template <int D> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + 255) / 256]; };
+template <int D> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + ATT_NT - 1) / ATT_NT]; };
 template <int D>
 __device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<D>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + 255) / 256;
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + ATT_NT - 1) / ATT_NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * ATT_NT;
     const int r = c / CPR, cc = (c % CPR) * 8;
     rg.v[i] = make_uint4(0, 0, 0, 0);
     if (c < F::BI * CPR && cc < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
@@ -56,22 +59,22 @@ __device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<
 template <int D>
 __device__ inline void commit_row(const RowRegs<D>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + 255) / 256;
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + ATT_NT - 1) / ATT_NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * ATT_NT;
     if (c < F::BI * CPR) *reinterpret_cast<uint4*>(lds + (c / CPR) * F::LDR + (c % CPR) * 8) = rg.v[i];
   }
 }
 // T tile: [D rows][BI cols] sub-matrix of a transposed copy (row stride gs) -> LDS [DO][LDT], rows D..DO zero filled.
-template <int D> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + 255) / 256]; };
+template <int D> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + ATT_NT - 1) / ATT_NT]; };
 template <int D>
 __device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + 255) / 256;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + ATT_NT - 1) / ATT_NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * ATT_NT;
     const int r = c / CPR, cc = (c % CPR) * 8;
     rg.v[i] = make_uint4(0, 0, 0, 0);
     if (c < F::DO * CPR && r < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
@@ -80,10 +83,10 @@ __device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D>& 
 template <int D>
 __device__ inline void commit_t(const TRegs<D>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + 255) / 256;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + ATT_NT - 1) / ATT_NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * ATT_NT;
     if (c < F::DO * CPR) {                      // rows are 8-byte (not 16-byte) aligned: two ds_write_b64
       bf16* dst = lds + (c / CPR) * F::LDT + (c % CPR) * 8;
       *reinterpret_cast<uint2*>(dst) = make_uint2(rg.v[i].x, rg.v[i].y);
@@ -139,13 +142,13 @@ struct FusedArgs {
 // kernels need, so the L x L probabilities are never materialised for the fused layers.  Same tiling as below:
 // lane <-> query, so the running max / sum and the rescale of the accumulator are register-local.
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
+__global__ __launch_bounds__(ATT_NT) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[F::ROW_ELEMS + F::T_ELEMS];
   bf16* sK = sm; bf16* sVT = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const int q = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* VTp = a.VT + ((long)b * a.H + h) * D * a.L;
@@ -224,13 +227,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(FusedArgs a, bf16* O, flo
 
 // ------------------------------------------------------------------------------------------------ tangent
 template <int D>
-__global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
+__global__ __launch_bounds__(ATT_NT) void attn_jvp_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
   bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sVT = sdK + F::ROW_ELEMS; bf16* sdVT = sVT + F::T_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const int q = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
   const bf16* Kp = a.K + b * LC + h * D;
@@ -324,13 +327,13 @@ __global__ __launch_bounds__(256) void attn_jvp_kernel(FusedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ adjoint, query-major (gQ)
 template <int D>
-__global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
+__global__ __launch_bounds__(ATT_NT) void attn_adj_q_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
   bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const int q = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
@@ -413,14 +416,14 @@ __global__ __launch_bounds__(256) void attn_adj_q_kernel(FusedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
 template <int D>
-__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
+__global__ __launch_bounds__(ATT_NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
   __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
   bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS; bf16* sQT = sgO + F::ROW_ELEMS; bf16* sgOT = sQT + F::T_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
-  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  const int key = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
   const long LCo = (long)a.L * a.Co;
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* st
 }
 
 int fused_attention_supported(int dtype, int d, int L, int kv_const) {
-  return dtype == DT_BF16 && !kv_const && (d == 40 || d == 80) && L >= 1024 && L % 128 == 0;
+  return dtype == DT_BF16 && !kv_const && (d == 40 || d == 80) && L >= 1024 && L % (ATT_WAVES * 32) == 0;
 }
 
 int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st) {
@@ -577,9 +580,9 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
 
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / 128, batch * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, dim3(256), 0, st, a, (bf16*)O, stats);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, dim3(256), 0, st, a, (bf16*)O, stats);
+  dim3 grid(f.L / (ATT_WAVES * 32), batch * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, dim3(ATT_NT), 0, st, a, (bf16*)O, stats);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, dim3(ATT_NT), 0, st, a, (bf16*)O, stats);
   else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -587,9 +590,9 @@ int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* sta
 
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / 128, nt * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_jvp_kernel<40>), grid, dim3(256), 0, st, a);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_jvp_kernel<80>), grid, dim3(256), 0, st, a);
+  dim3 grid(f.L / (ATT_WAVES * 32), nt * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_jvp_kernel<40>), grid, dim3(ATT_NT), 0, st, a);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_jvp_kernel<80>), grid, dim3(ATT_NT), 0, st, a);
   else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -597,13 +600,13 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
 
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / 128, nt * f.H);
+  dim3 grid(f.L / (ATT_WAVES * 32), nt * f.H);
   if (f.d == 40) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(ATT_NT), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(ATT_NT), 0, st, a);
   } else if (f.d == 80) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<80>), grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<80>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_q_kernel<80>), grid, dim3(ATT_NT), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<80>), grid, dim3(ATT_NT), 0, st, a);
   } else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;
