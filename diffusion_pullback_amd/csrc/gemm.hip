@@ -437,12 +437,16 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (g_force_tile == 257) return 256;
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
+  if (g_force_tile >= 512 && g_force_tile <= 515) return g_force_tile;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
   // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
   // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
+  // BK = 64 ring (gemm_ring64.hip: whole-line DMA + in-wave fragment prefetch, 128x128 tile, 2 stages -> 2 blocks/CU):
+  // ahead of the BK = 32 rings by 10-35 % from ~8 stages of K on, with split-K when the tiles leave CUs idle
+  if (a.K >= 512 && (t128 >= 200 || a.K >= 2048)) return 515;
   // (3-stage ring = 48 KiB -> 3 blocks/CU measured slightly ahead of 4 stages / 2 blocks and 2 stages / 5 blocks)
   if (t128 >= 400) return 130;                  // chip filled by 128x128 tiles
   if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
@@ -453,13 +457,17 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256) ? 128 : 64;
-  const int TMm = tile == 256 ? 256 : T;
+  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256 || tile >= 512) ? 128 : 64;
+  const int TMm = (tile == 256 || tile == 513) ? 256 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;
   if (g_force_splitk) s = g_force_splitk;
-  else {
+  else if (tile >= 512) {                       // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
+    if (tiles >= 384) return 1;
+    s = std::max<long>(1, (512 + tiles / 2) / tiles);
+    s = std::min<long>(s, std::max(1, nk / 16));
+  } else {
     if (tiles >= 256 || nk < 64) return 1;      // only when CUs would idle and K is long enough to amortise the slabs
     s = (1024 + tiles - 1) / tiles;
     s = std::min<long>(s, nk / 12);             // keep >= 12 K steps per block (ring depth 3)
@@ -525,7 +533,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   const int Z = a.Z1 * a.Z2;
   if (int dt = gemm_uses_dma(dtype, a)) {
     a.splitk = gemm_pick_splitk_dma(a, dt);
-    if (int r = launch_gemm_dma(a, dt, st)) return r;
+    if (int r = dt >= 512 ? launch_gemm_ring64(a, dt, st) : launch_gemm_dma(a, dt, st)) return r;
     if (a.splitk > 1) {
       long total = (long)a.M * a.N * Z / 4;
       unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));

@@ -40,6 +40,7 @@ int gemm_uses_big_tile(int dtype, const GemmArgs& a);
 void gemm_debug_set(int tile, int splitk, int kch);
 int gemm_kch(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st);   // bf16, single operand pair, no split-K (gemm_dma.hip); tile 128 | 64 | 66 (64 with a 6-stage ring)
+int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st);   // BK = 64 ring (gemm_ring64.hip); tile 512 | 513 | 514 | 515
 int gemm_uses_dma(int dtype, const GemmArgs& a);   // 0 = register-staged kernel, else the tile code for launch_gemm_dma
 void gemm_debug_dma_auto(int on);
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
