@@ -24,10 +24,11 @@ namespace dpb {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int ATT_WAVES = 8;                    // waves per block: 8 x 32 = 256 outer rows share every streamed tile
-constexpr int ATT_NT = ATT_WAVES * 64;
+constexpr int att_waves(int d) { return d > 80 ? 4 : 8; }   // waves per block: 8 x 32 = 256 outer rows share every streamed tile
+                                                            // (head dim 160: 4 waves, the fragments need the 512-register budget)
 
 template <int D> struct FA {
+  static constexpr int WAVES = att_waves(D), NT = WAVES * 64;
   static constexpr int NS = (D + 15) / 16;      // k-steps of the score products
   static constexpr int DP = NS * 16;            // padded head dim (score products)
   static constexpr int ND = (D + 31) / 32;      // 32-wide output tiles over the head dim
@@ -43,14 +44,14 @@ template <int D> struct FA {
 // Register-staged tile loads: fetch() issues the global loads of the NEXT stage before the MFMAs of the current one,
 // commit() writes them to LDS after the barrier, so HBM/L2 latency overlaps the compute.
 // Row tile: [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled.
-template <int D> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + ATT_NT - 1) / ATT_NT]; };
+template <int D> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + FA<D>::NT - 1) / FA<D>::NT]; };
 template <int D>
 __device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<D>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + ATT_NT - 1) / ATT_NT;
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + F::NT - 1) / F::NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * ATT_NT;
+    const int c = tid + i * F::NT;
     const int r = c / CPR, cc = (c % CPR) * 8;
     rg.v[i] = make_uint4(0, 0, 0, 0);
     if (c < F::BI * CPR && cc < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
@@ -59,22 +60,22 @@ __device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<
 template <int D>
 __device__ inline void commit_row(const RowRegs<D>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + ATT_NT - 1) / ATT_NT;
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + F::NT - 1) / F::NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * ATT_NT;
+    const int c = tid + i * F::NT;
     if (c < F::BI * CPR) *reinterpret_cast<uint4*>(lds + (c / CPR) * F::LDR + (c % CPR) * 8) = rg.v[i];
   }
 }
 // T tile: [D rows][BI cols] sub-matrix of a transposed copy (row stride gs) -> LDS [DO][LDT], rows D..DO zero filled.
-template <int D> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + ATT_NT - 1) / ATT_NT]; };
+template <int D> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + FA<D>::NT - 1) / FA<D>::NT]; };
 template <int D>
 __device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + ATT_NT - 1) / ATT_NT;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + F::NT - 1) / F::NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * ATT_NT;
+    const int c = tid + i * F::NT;
     const int r = c / CPR, cc = (c % CPR) * 8;
     rg.v[i] = make_uint4(0, 0, 0, 0);
     if (c < F::DO * CPR && r < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
@@ -83,10 +84,10 @@ __device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D>& 
 template <int D>
 __device__ inline void commit_t(const TRegs<D>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + ATT_NT - 1) / ATT_NT;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + F::NT - 1) / F::NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * ATT_NT;
+    const int c = tid + i * F::NT;
     if (c < F::DO * CPR) {                      // rows are 8-byte (not 16-byte) aligned: two ds_write_b64
       bf16* dst = lds + (c / CPR) * F::LDT + (c % CPR) * 8;
       *reinterpret_cast<uint2*>(dst) = make_uint2(rg.v[i].x, rg.v[i].y);
@@ -142,13 +143,13 @@ struct FusedArgs {
 // kernels need, so the L x L probabilities are never materialised for the fused layers.  Same tiling as below:
 // lane <-> query, so the running max / sum and the rescale of the accumulator are register-local.
 template <int D>
-__global__ __launch_bounds__(ATT_NT) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
+__global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[F::ROW_ELEMS + F::T_ELEMS];
   bf16* sK = sm; bf16* sVT = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
-  const int q = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
+  const int q = blockIdx.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* VTp = a.VT + ((long)b * a.H + h) * D * a.L;
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(ATT_NT) void attn_fwd_kernel(FusedArgs a, bf16* O, 
 
 // ------------------------------------------------------------------------------------------------ tangent
 template <int D>
-__global__ __launch_bounds__(ATT_NT) void attn_jvp_kernel(FusedArgs a) {
+__global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
   bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sVT = sdK + F::ROW_ELEMS; bf16* sdVT = sVT + F::T_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
-  const int q = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
+  const int q = blockIdx.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
   const bf16* Kp = a.K + b * LC + h * D;
@@ -327,13 +328,13 @@ __global__ __launch_bounds__(ATT_NT) void attn_jvp_kernel(FusedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ adjoint, query-major (gQ)
 template <int D>
-__global__ __launch_bounds__(ATT_NT) void attn_adj_q_kernel(FusedArgs a) {
+__global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
   bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
-  const int q = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
+  const int q = blockIdx.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
@@ -416,14 +417,14 @@ __global__ __launch_bounds__(ATT_NT) void attn_adj_q_kernel(FusedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
 template <int D>
-__global__ __launch_bounds__(ATT_NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
+__global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
   __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
   bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS; bf16* sQT = sgO + F::ROW_ELEMS; bf16* sgOT = sQT + F::T_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
-  const int key = blockIdx.x * (ATT_WAVES * 32) + wave * 32 + l31;
+  const int key = blockIdx.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
   const long LCo = (long)a.L * a.Co;
@@ -531,6 +532,160 @@ __global__ __launch_bounds__(ATT_NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------ constant-K/V (cross) attention
+// Text-conditioned layers: K and V are projections of the prompt embedding, which does not depend on x_t, so only the
+// query side carries a tangent / cotangent and both passes are the SAME row-local map
+//     Y_i = c_out * sum_j W_ij B_j ,   W = P o (c_in X A^T - delta) ,   delta_i = sum_j P_ij (c_in X A^T)_ij ,
+// tangent: (X, A, B, c_in, c_out) = (dQ, K, V, scale, 1) -> dO;   adjoint: (gO, V, K, 1, scale) -> gQ.
+// The 77 keys fit one tile (padded to 96 = three 32-key MFMA blocks, masked), so P is recomputed in registers from Q
+// and K (fp32, exact softmax statistics) instead of being re-read from the stored bf16 probabilities; one launch
+// replaces GEMM + softmax-Jacobian + GEMM and their [nt][H][L][80] round trips.  Same lane <-> query layout as above.
+struct CrossArgs {
+  const bf16 *Q, *K, *V;              // primal q [B][L][C], k / v [B][Lk][Ck]
+  const bf16* BT;                     // per-head transpose of the second-stage operand B: [B][H][d][Lkp]
+  const bf16* X; bf16* Y;             // [nt][L][Cx] in, [nt][L][Cy] out
+  int L, Lk, Lkp, C, Ck, Cx, Cy, H, kps, a_is_v, accumulate;
+  float scale, c_in, c_out;
+};
+constexpr int XKEYS = 96, XLDT = XKEYS + 4;
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
+  using F = FA<D>;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * XKEYS * F::LDR + F::DO * XLDT];
+  bf16* sK = sm; bf16* sV = sK + XKEYS * F::LDR; bf16* sBT = sV + XKEYS * F::LDR;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int j = blockIdx.y / a.H, h = blockIdx.y % a.H, b = j / a.kps;
+  const int q = blockIdx.x * (nthr >> 1) + wave * 32 + l31;
+  {   // K, V rows (zero beyond Lk / D) and B^T (zero beyond D / Lkp): one small tile each, loaded once per block
+    constexpr int CPR = F::DP / 8;
+    const bf16* Kp = a.K + (long)b * a.Lk * a.Ck + h * D;
+    const bf16* Vp = a.V + (long)b * a.Lk * a.Ck + h * D;
+    for (int c = tid; c < XKEYS * CPR; c += nthr) {
+      const int r = c / CPR, cc = (c % CPR) * 8;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+      if (r < a.Lk && cc < D) {
+        kv = *reinterpret_cast<const uint4*>(Kp + (long)r * a.Ck + cc);
+        vv = *reinterpret_cast<const uint4*>(Vp + (long)r * a.Ck + cc);
+      }
+      *reinterpret_cast<uint4*>(sK + r * F::LDR + cc) = kv;
+      *reinterpret_cast<uint4*>(sV + r * F::LDR + cc) = vv;
+    }
+    constexpr int CPT = XKEYS / 8;
+    const bf16* Bp = a.BT + ((long)b * a.H + h) * D * a.Lkp;
+    for (int c = tid; c < F::DO * CPT; c += nthr) {
+      const int r = c / CPT, cc = (c % CPT) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < D && cc < a.Lkp) v = *reinterpret_cast<const uint4*>(Bp + (long)r * a.Lkp + cc);
+      bf16* dst = sBT + r * XLDT + cc;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+      *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
+    }
+  }
+  bf16x8 qf[F::NS], xf[F::NS];
+  load_outer_frags<D>(a.Q + (long)b * a.L * a.C + (long)q * a.C + h * D, qf, lhi);
+  load_outer_frags<D>(a.X + (long)j * a.L * a.Cx + (long)q * a.Cx + h * D, xf, lhi);
+  __syncthreads();
+  const bf16* sA = a.a_is_v ? sV : sK;
+  f32x16 s[3], t[3];
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kb][r] = t[kb][r] = 0.f;
+#pragma unroll
+    for (int stp = 0; stp < F::NS; ++stp) {
+      s[kb] = MFMA(lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), qf[stp], s[kb]);
+      t[kb] = MFMA(lds_a_frag(sA, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), xf[stp], t[kb]);
+    }
+  }
+  const float c2 = a.scale * 1.44269504088896f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      s[kb][r] = key < a.Lk ? s[kb][r] * c2 : -INFINITY;
+      mx = fmaxf(mx, s[kb][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - mx); l += s[kb][r]; }
+  l += __shfl_xor(l, 32, 64);
+  const float il = 1.f / l;
+  float delta = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[kb][r] *= il;                                   // P
+      t[kb][r] *= a.c_in * s[kb][r];                    // P o (c_in X A^T)
+      delta += t[kb][r];
+    }
+  delta += __shfl_xor(delta, 32, 64);
+  f32x16 acc[F::ND];
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb) {
+    float w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = t[kb][r] - delta * s[kb][r];
+    bf16x8 wb[2];
+    pack_b(w, wb);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int d = 0; d < F::ND; ++d)
+        acc[d] = MFMA(lds_t_frag(sBT, d * 32 + l31, XLDT, kb * 32 + ks * 16, lhi), wb[ks], acc[d]);
+  }
+  bf16* Yp = a.Y + (long)j * a.L * a.Cy + (long)q * a.Cy + h * D;
+#pragma unroll
+  for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = d * 32 + 8 * g + 4 * lhi;
+      if (col < D) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a.c_out * acc[d][g * 4 + i];
+        if (a.accumulate) {
+          uint2 ov = *reinterpret_cast<const uint2*>(Yp + col);
+          v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
+          v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2*>(Yp + col) =
+            make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+      }
+    }
+}
+
+int cross_attention_supported(int dtype, int d, int Lq, int Lk, int kv_const) {
+  return dtype == DT_BF16 && kv_const && (d == 40 || d == 80 || d == 160) && Lk <= XKEYS && Lq % 32 == 0 && (Lq >= 128 ? Lq % 128 == 0 : true);
+}
+
+int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st) {
+  CrossArgs a;
+  a.Q = (const bf16*)f.Q; a.K = (const bf16*)f.K; a.V = (const bf16*)f.V; a.BT = (const bf16*)f.BT;
+  a.X = (const bf16*)f.X; a.Y = (bf16*)f.Y;
+  a.L = f.L; a.Lk = f.Lk; a.Lkp = f.Lkp; a.C = f.C; a.Ck = f.Ck; a.Cx = f.Cx; a.Cy = f.Cy; a.H = f.H; a.kps = f.kps;
+  a.a_is_v = f.adjoint; a.accumulate = f.accumulate; a.scale = f.scale;
+  a.c_in = f.adjoint ? 1.f : f.scale; a.c_out = f.adjoint ? f.scale : 1.f;
+  const int waves = f.L >= 128 ? 4 : f.L / 32;
+  dim3 grid(f.L / (waves * 32), nt * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_cross_kernel<40>), grid, dim3(waves * 64), 0, st, a);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_cross_kernel<80>), grid, dim3(waves * 64), 0, st, a);
+  else if (f.d == 160) hipLaunchKernelGGL((attn_cross_kernel<160>), grid, dim3(waves * 64), 0, st, a);
+  else { set_error("cross attention: head dim %d unsupported", f.d); return -1; }
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
 // row statistics of the primal probabilities from the materialised scaled scores S (before softmax):
 // one wave per row; stats[row] = (max, 1 / sum exp(S - max))
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* stats, long nrows, int Lk, int ld) {
@@ -558,7 +713,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* st
 }
 
 int fused_attention_supported(int dtype, int d, int L, int kv_const) {
-  return dtype == DT_BF16 && !kv_const && (d == 40 || d == 80) && L >= 1024 && L % (ATT_WAVES * 32) == 0;
+  return dtype == DT_BF16 && !kv_const && (d == 40 || d == 80 || d == 160) && L >= 256 && L % (att_waves(d) * 32) == 0;
 }
 
 int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st) {
@@ -580,9 +735,10 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
 
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / (ATT_WAVES * 32), batch * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, dim3(ATT_NT), 0, st, a, (bf16*)O, stats);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, dim3(ATT_NT), 0, st, a, (bf16*)O, stats);
+  dim3 grid(f.L / (att_waves(f.d) * 32), batch * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a, (bf16*)O, stats);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a, (bf16*)O, stats);
+  else if (f.d == 160) hipLaunchKernelGGL((attn_fwd_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a, (bf16*)O, stats);
   else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -590,9 +746,10 @@ int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* sta
 
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / (ATT_WAVES * 32), nt * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_jvp_kernel<40>), grid, dim3(ATT_NT), 0, st, a);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_jvp_kernel<80>), grid, dim3(ATT_NT), 0, st, a);
+  dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
+  if (f.d == 40) hipLaunchKernelGGL((attn_jvp_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+  else if (f.d == 80) hipLaunchKernelGGL((attn_jvp_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+  else if (f.d == 160) hipLaunchKernelGGL((attn_jvp_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
   else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -600,13 +757,16 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
 
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / (ATT_WAVES * 32), nt * f.H);
+  dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
   if (f.d == 40) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(ATT_NT), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(ATT_NT), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
   } else if (f.d == 80) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<80>), grid, dim3(ATT_NT), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<80>), grid, dim3(ATT_NT), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_q_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+  } else if (f.d == 160) {
+    hipLaunchKernelGGL((attn_adj_q_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
   } else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;

@@ -46,7 +46,7 @@ struct Buf {
 
 struct AttnPlan {            // per attention op, persisted from the primal pass
   int heads = 0, d = 0, Lq = 0, Lk = 0, Lqp = 0, Lkp = 0;
-  bool kv_const = false, fused = false;
+  bool kv_const = false, fused = false, cross = false;   // cross: constant K/V, one-launch tangent / adjoint (attn_cross_kernel)
   int oq = 0, ok = 0, ov = 0;                      // column offsets of q / k / v inside their buffers (fused QKV projection)
   size_t P = 0, PT = 0, KT = 0, VT = 0, QT = 0, stats = 0;   // offsets
 };
@@ -422,6 +422,15 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 5 * nt * H;
     return launch_attn_jvp_fused(f, nt, e->stream);
   }
+  if (p.cross) {   // constant K/V: dO = [P o (scale dQ K^T - delta)] V in one launch
+    CrossAttnArgs f;
+    f.Q = x.Q; f.K = x.K; f.V = x.V; f.BT = ws + p.VT; f.X = t.Q; f.Y = t.O;
+    f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = t.ldq; f.Cy = t.ldo;
+    f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 0; f.scale = scale;
+    e->n_launch++;
+    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
+    return launch_attn_cross(f, nt, e->stream);
+  }
   GemmArgs g;   // dS = scale * dQ K^T
   g.A = t.Q; g.lda = t.ldq; g.sA1 = (long)p.Lq * t.ldq; g.sA2 = p.d;
   g.B = x.K; g.ldb = x.ldk; g.sB1 = (long)p.Lk * x.ldk; g.sB2 = p.d; g.divB = kps;
@@ -474,6 +483,17 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;
     if (int r = launch_attn_adj_fused(f, nt, e->stream)) return r;
     e->ginit[d.in0] = e->ginit[d.in1] = e->ginit[d.in2] = 1;
+    return 0;
+  }
+  if (p.cross) {   // constant K/V: gQ (+)= scale [P o (gO V^T - delta)] K in one launch
+    CrossAttnArgs f;
+    f.Q = x.Q; f.K = x.K; f.V = x.V; f.BT = ws + p.KT; f.X = gO; f.Y = (void*)c.Q;
+    f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = c.ldo; f.Cy = c.ldq;
+    f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 1; f.accumulate = accQ; f.scale = scale;
+    e->n_launch++;
+    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
+    if (int r = launch_attn_cross(f, nt, e->stream)) return r;
+    e->ginit[d.in0] = 1;
     return 0;
   }
   GemmArgs g;   // gP = gO V^T
@@ -646,7 +666,10 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       const size_t H = p.heads;
       // long bf16 self-attention layers run the flash-style kernels (attn_fused.hip): no L x L object is ever stored
       p.fused = fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN") &&
+                p.Lq >= (getenv("DPB_FUSED_ATTN_MIN_L") ? atoi(getenv("DPB_FUSED_ATTN_MIN_L")) : 256) &&      // tuning override
                 e->bufs[d.in0].C == e->bufs[d.in1].C && e->bufs[d.in0].C == e->bufs[d.in2].C;
+      p.cross = cross_attention_supported(e->dtype, p.d, p.Lq, p.Lk, p.kv_const) && !getenv("DPB_NO_CROSS_ATTN") &&
+                e->bufs[d.in1].C == e->bufs[d.in2].C;
       if (!p.fused) p.P = take((size_t)e->maxB * H * p.Lq * p.Lkp * es);
       p.VT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
       p.KT = take((size_t)e->maxB * H * p.d * p.Lkp * es);

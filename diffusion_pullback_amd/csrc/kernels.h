@@ -94,6 +94,16 @@ struct FusedAttnArgs {
   float scale = 1.f;
 };
 int fused_attention_supported(int dtype, int d, int L, int kv_const);
+// constant-K/V (cross) attention tangent / adjoint in one launch (attn_fused.hip): Y = c_out [P o (c_in X A^T - delta)] B
+struct CrossAttnArgs {
+  const void *Q = nullptr, *K = nullptr, *V = nullptr;   // primal q [B][L][C]; k, v [B][Lk][Ck] (column windows allowed)
+  const void* BT = nullptr;                              // per-head transpose [B][H][d][Lkp] of V (tangent) or K (adjoint)
+  const void* X = nullptr; void* Y = nullptr;            // dQ -> dO (tangent) or gO -> gQ (adjoint)
+  int L = 0, Lk = 0, Lkp = 0, C = 0, Ck = 0, Cx = 0, Cy = 0, H = 0, d = 0, kps = 1, adjoint = 0, accumulate = 0;
+  float scale = 1.f;
+};
+int cross_attention_supported(int dtype, int d, int Lq, int Lk, int kv_const);
+int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st);
 int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st);
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st);   // primal O + row statistics
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st);

@@ -80,21 +80,22 @@ def test_small_ddpm_primal_jvp_vjp(dtype):
                  [("down", 0), ("down", 1), ("down", 2), ("mid", 0), ("up", 2), ("up", 1), ("up", 0), "eps"], dtype)
 
 
-@pytest.mark.parametrize("dtype,boc", [(torch.float32, (320, 640)), (torch.bfloat16, (320, 640)), (torch.bfloat16, (640, 640))])
-def test_medium_sd_shapes(dtype, boc):
-    """SD-like widths with the real head dims (40/80), 77-token context (padded to 80), 128x128 GEMM tiles; in bf16 the
-    L=1024 self-attention layers run the fused tangent/adjoint attention kernels (head dim 40 and 80)."""
+@pytest.mark.parametrize("dtype,boc,size", [(torch.float32, (320, 640), 32), (torch.bfloat16, (320, 640), 32), (torch.bfloat16, (640, 640), 32),
+                                            (torch.bfloat16, (1280, 1280), 16)])
+def test_medium_sd_shapes(dtype, boc, size):
+    """SD-like widths with the real head dims (40/80/160), 77-token context (padded to 80), 128x128 GEMM tiles; in bf16 the
+    L=1024 (head dim 40, 80) and L=256 (head dim 160) self-attention layers run the fused tangent/adjoint attention kernels."""
     from diffusion_pullback_amd import PullbackUNet
     from oracle import unet_sd
     cfg = unet_sd.SDConfig(block_out_channels=boc, layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
-                           heads=(8, 8), cross_dim=768, sample_size=32, ctx_len=77)
+                           heads=(8, 8), cross_dim=768, sample_size=size, ctx_len=77)
     p = unet_sd.init_params(cfg, seed=1)
     g = torch.Generator().manual_seed(2)
-    z = torch.randn(1, 4, 32, 32, generator=g); ctx = torch.randn(1, 77, 768, generator=g); t = torch.tensor(696.2727)
+    z = torch.randn(1, 4, size, size, generator=g); ctx = torch.randn(1, 77, 768, generator=g); t = torch.tensor(696.2727)
     net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=1, max_rank=4, upto=("mid", 0), verbose=False)
     fwd = lambda a, tap: unet_sd.forward(p, cfg, a, t, ctx.expand(a.shape[0], -1, -1), stop=tap)
     errs = check_passes(net, fwd, z, float(t), ctx, [("down", 0), ("mid", 0)], dtype, k=2)
-    print(dtype, boc, errs)
+    print(dtype, boc, size, errs)
 
 
 def test_ddpm_forward_matches_reference_golden():
