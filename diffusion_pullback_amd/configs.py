@@ -219,3 +219,96 @@ def sd_init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.
         if only_prefix is None or name.startswith(only_prefix):
             p[name] = t.to(dtype)
     return p
+
+
+# =================================================================== SD image autoencoder (AutoencoderKL)
+@dataclass(frozen=True)
+class VAEConfig:
+    """diffusers==0.11 AutoencoderKL as shipped with runwayml/stable-diffusion-v1-5 (vae/config.json) -- the object
+    behind ``pipe.vae`` at reference src/modules/edit.py:144-146 (encode) and :476-480 (decode)."""
+    in_channels: int = 3
+    out_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    groups: int = 32
+    gn_eps: float = 1e-6
+    sample_size: int = 512                         # image side; latents are sample_size / 2^(len(boc)-1)
+    scaling_factor: float = 0.18215                # edit.py:146 / :477
+
+    @property
+    def latent_size(self) -> int:
+        return self.sample_size >> (len(self.block_out_channels) - 1)
+
+
+SD15_VAE = VAEConfig()
+
+
+def vae_param_shapes(cfg: VAEConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    boc = cfg.block_out_channels
+    L2 = 2 * cfg.latent_channels
+
+    def conv(n, ci, co, k=3):
+        s[n + ".weight"] = (co, ci, k, k); s[n + ".bias"] = (co,)
+
+    def lin(n, ci, co):
+        s[n + ".weight"] = (co, ci); s[n + ".bias"] = (co,)
+
+    def norm(n, c):
+        s[n + ".weight"] = (c,); s[n + ".bias"] = (c,)
+
+    def resnet(n, ci, co):
+        norm(n + ".norm1", ci); conv(n + ".conv1", ci, co); norm(n + ".norm2", co); conv(n + ".conv2", co, co)
+        if ci != co:
+            conv(n + ".conv_shortcut", ci, co, 1)
+
+    def mid(n, c):
+        resnet(n + ".resnets.0", c, c)
+        a = n + ".attentions.0"
+        norm(a + ".group_norm", c)
+        for q in ("query", "key", "value", "proj_attn"):
+            lin(a + "." + q, c, c)
+        resnet(n + ".resnets.1", c, c)
+
+    conv("encoder.conv_in", cfg.in_channels, boc[0])
+    ch = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", ch, co)
+            ch = co
+        if i != len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", ch, ch)
+    mid("encoder.mid_block", ch)
+    norm("encoder.conv_norm_out", ch)
+    conv("encoder.conv_out", ch, L2)
+    conv("quant_conv", L2, L2, 1)
+    conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+    rev = tuple(reversed(boc))
+    conv("decoder.conv_in", cfg.latent_channels, rev[0])
+    mid("decoder.mid_block", rev[0])
+    ch = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", ch, co)
+            ch = co
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", ch, ch)
+    norm("decoder.conv_norm_out", ch)
+    conv("decoder.conv_out", ch, cfg.out_channels)
+    return s
+
+
+def vae_init_params(cfg: VAEConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32) -> Params:
+    """Seeded synthetic weights at the exact architecture shapes (CPU generator)."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shp in vae_param_shapes(cfg).items():
+        if name.endswith(".weight") and len(shp) == 1:
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g)
+        else:
+            t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
+        p[name] = t.to(dtype)
+    return p

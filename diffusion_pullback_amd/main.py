@@ -7,7 +7,8 @@ Keeps the reference's live-path flags and preset rules so its scripts run unchan
 constants of main.py:30-34 (op='mid', block_idx=0, vis_num=4, vis_num_pc=2, pca_rank=2) as defaults.
 Flags of the reference's dead experiments are accepted and ignored with a note.
 New flags (not in the reference): --pca_rank, --op, --block_idx, --dtype bf16, --weights (state-dict
-file; default: seeded synthetic weights, there are no checkpoints offline), --net_scale (reduced nets).
+file; default: seeded synthetic weights, there are no checkpoints offline), --net_scale (reduced nets),
+--vae (none | synthetic | <state-dict file>: decode the edited latents to PNGs with the on-device AutoencoderKL).
 """
 from __future__ import annotations
 
@@ -52,7 +53,7 @@ _FLAGS = [  # (name, type, default) -- define_argparser.py:20-110, live path onl
     ("run_edit_local_encoder_pullback_zt", str2bool, False),
     # new
     ("pca_rank", int, 2), ("op", str, "mid"), ("block_idx", int, 0), ("vis_num", int, 4), ("vis_num_pc", int, 2), ("weights", str, ""),
-    ("net_scale", str, "full"),
+    ("net_scale", str, "full"), ("vae", str, "none"),
 ]
 
 
@@ -124,12 +125,23 @@ def build_unet(args) -> PullbackUNet:
     return PullbackUNet("ddpm", cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=5, max_rank=max(args.pca_rank, 2))
 
 
+def build_vae(args):
+    """``pipe.vae`` of the reference (edit.py:144-146, :476-480) on the HIP engine; None keeps latents as the output."""
+    if args.vae == "none" or not args.is_stable_diffusion:
+        return None
+    from .vae import AutoencoderKL
+    small = args.net_scale != "full"
+    cfg = cf.SD15_VAE if not small else cf.VAEConfig(block_out_channels=(32, 64), layers_per_block=1, groups=8, sample_size=2 * args.image_size)
+    params = cf.vae_init_params(cfg, seed=args.seed) if args.vae == "synthetic" else torch.load(args.vae, map_location="cpu")
+    return AutoencoderKL(cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=1)
+
+
 def main(argv=None):
     args = preset(parse_args(argv))
     unet = build_unet(args)
     if args.is_stable_diffusion:
         print("is stable-diffusion")
-        edit = EditStableDiffusion(args, unet=unet)
+        edit = EditStableDiffusion(args, unet=unet, vae=build_vae(args))
     else:
         print("is NOT stable-diffusion")
         edit = EditUncondDiffusion(args, unet=unet)

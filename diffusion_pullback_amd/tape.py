@@ -311,3 +311,76 @@ def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None)
     o = t.conv("conv_out", n, (r, r), cfg.out_channels)
     t.tap("eps", o, cfg.out_channels, r, r)
     return t
+
+
+# =================================================================== SD image autoencoder (primal only)
+def _vae_blocks(t: Tape, cfg):
+    G, eps = cfg.groups, cfg.gn_eps
+
+    def resnet(pre, x, cin, cout, r):
+        n1 = t.groupnorm(pre + ".norm1", x, G, eps, True)
+        c1 = t.conv(pre + ".conv1", n1, (r, r), cout, need_adj=False)
+        n2 = t.groupnorm(pre + ".norm2", c1, G, eps, True)
+        sc = t.conv(pre + ".conv_shortcut", x, (r, r), cout, ks=1, need_adj=False) if cin != cout else x
+        return t.conv(pre + ".conv2", n2, (r, r), cout, res=sc, need_adj=False)
+
+    def mid(pre, x, c, r):
+        x = resnet(pre + ".resnets.0", x, c, c, r)
+        a = pre + ".attentions.0"
+        n = t.groupnorm(a + ".group_norm", x, G, eps, False)
+        qkv = t.conv((a + ".query", a + ".key", a + ".value"), n, (r, r), 3 * c, ks=1, need_adj=False)
+        x = t.conv(a + ".proj_attn", t.attention(qkv, qkv, qkv, 1, c, (0, c, 2 * c)), (r, r), c, ks=1, res=x, need_adj=False)
+        return resnet(pre + ".resnets.1", x, c, c, r)
+
+    return resnet, mid
+
+
+def build_vae_encoder(cfg, params, dtype, device) -> Tape:
+    """image [S,S,3] -> moments [S/8,S/8,2*latent] (mean | logvar); diffusers AutoencoderKL.encode + quant_conv
+    (the object behind reference src/modules/edit.py:144-146).  cfg: configs.VAEConfig."""
+    t = Tape(params, dtype, device)
+    resnet, mid = _vae_blocks(t, cfg)
+    boc = cfg.block_out_channels
+    r = cfg.sample_size
+    t.temb_in = t.buf(1, 8, L.BUF_SHARED)          # the autoencoder has no time embedding; the engine wants the slot
+    t.x = t.buf(r * r, _r8(cfg.in_channels))
+    h = t.conv("encoder.conv_in", t.x, (r, r), boc[0], need_adj=False)
+    ch = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            h = resnet(f"encoder.down_blocks.{i}.resnets.{j}", h, ch, co, r)
+            ch = co
+        if i != len(boc) - 1:
+            h = t.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", h, (r, r), ch, stride=2, pad=0, need_adj=False)   # F.pad (0,1,0,1)
+            r //= 2
+    h = mid("encoder.mid_block", h, ch, r)
+    n = t.groupnorm("encoder.conv_norm_out", h, cfg.groups, cfg.gn_eps, True)
+    o = t.conv("encoder.conv_out", n, (r, r), 2 * cfg.latent_channels, need_adj=False)
+    m = t.conv("quant_conv", o, (r, r), 2 * cfg.latent_channels, ks=1, need_adj=False)
+    t.tap("moments", m, 2 * cfg.latent_channels, r, r)
+    return t
+
+
+def build_vae_decoder(cfg, params, dtype, device) -> Tape:
+    """latent [S/8,S/8,4] -> image [S,S,3]; post_quant_conv + diffusers AutoencoderKL.decode (edit.py:476-478)."""
+    t = Tape(params, dtype, device)
+    resnet, mid = _vae_blocks(t, cfg)
+    rev = tuple(reversed(cfg.block_out_channels))
+    r = cfg.latent_size
+    t.temb_in = t.buf(1, 8, L.BUF_SHARED)
+    t.x = t.buf(r * r, _r8(cfg.latent_channels))
+    h = t.conv("post_quant_conv", t.x, (r, r), cfg.latent_channels, ks=1, need_adj=False)
+    h = t.conv("decoder.conv_in", h, (r, r), rev[0], need_adj=False)
+    h = mid("decoder.mid_block", h, rev[0], r)
+    ch = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            h = resnet(f"decoder.up_blocks.{i}.resnets.{j}", h, ch, co, r)
+            ch = co
+        if i != len(rev) - 1:
+            h = t.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", h, (r, r), ch, upsample=True, need_adj=False)
+            r *= 2
+    n = t.groupnorm("decoder.conv_norm_out", h, cfg.groups, cfg.gn_eps, True)
+    o = t.conv("decoder.conv_out", n, (r, r), cfg.out_channels, need_adj=False)
+    t.tap("image", o, cfg.out_channels, r, r)
+    return t

@@ -59,3 +59,25 @@ def test_tape_structure_sd15_and_ddpm():
     ts = build_sd(scfg, cf.sd_init_params(scfg), torch.bfloat16, "cpu", upto=("mid", 0))
     assert ("up", 0) not in ts.taps and ts.tap_shape[ts.taps[("mid", 0)]] == (64, 4, 4)
     assert all(c % 8 == 0 for _, c, _ in ts.buffers)
+
+
+def test_tape_structure_vae_and_cli_default():
+    """Image autoencoder tapes build without a GPU; the CLI keeps latents unless --vae is given."""
+    from diffusion_pullback_amd import configs as cf
+    from diffusion_pullback_amd import main as M
+    from diffusion_pullback_amd.tape import build_vae_decoder, build_vae_encoder
+    cfg = cf.VAEConfig(block_out_channels=(32, 64, 64), layers_per_block=1, groups=8, sample_size=32)
+    p = cf.vae_init_params(cfg)
+    d = build_vae_decoder(cfg, p, torch.bfloat16, "cpu")
+    assert d.tap_shape[d.taps["image"]] == (3, 32, 32) and d.buffers[d.x][:2] == (64, 8)          # 8x8 latent, 4 channels padded to 8
+    assert d.buffers[d.taps["image"]][1] == 8 and d.valid[d.taps["image"]] == 3
+    e = build_vae_encoder(cfg, p, torch.bfloat16, "cpu")
+    assert e.tap_shape[e.taps["moments"]] == (8, 8, 8) and e.buffers[e.x][:2] == (32 * 32, 8)
+    assert sum(1 for o in d.ops if o["kind"] == 4) == 1 and sum(1 for o in e.ops if o["kind"] == 4) == 1   # one attention op each
+    assert all(o["w"][1] == 0 for o in d.ops + e.ops if o["kind"] == 1)                              # primal only: no adjoint weights
+    full = cf.vae_param_shapes(cf.SD15_VAE)
+    assert cf.SD15_VAE.latent_size == 64 and full["decoder.conv_in.weight"] == (512, 4, 3, 3) and full["encoder.conv_out.weight"] == (8, 512, 3, 3)
+    args = M.preset(M.parse_args(["--note", "t", "--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Examples", "--edit_prompt", "x",
+                                  "--x_space_guidance_scale", "1", "--x_space_guidance_num_step", "4", "--edit_t", "0.7",
+                                  "--run_edit_local_encoder_pullback_zt", "True"]))
+    assert args.vae == "none" and M.build_vae(args) is None

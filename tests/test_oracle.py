@@ -97,3 +97,21 @@ def test_pullback_zt_xt_match_reference_utils(case):
         torch.testing.assert_close(s, sr, rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(vT, vr, rtol=1e-3, atol=1e-4)
         torch.testing.assert_close(u, ur, rtol=1e-3, atol=1e-4)
+
+
+def test_vae_oracle_shapes_and_param_count():
+    """AutoencoderKL restatement (PARITY UNPINNED, diffusers absent): published parameter count of the SD-1.5 VAE and
+    the encode / decode shape contract of reference src/modules/edit.py:144-146, :476-480."""
+    import math
+    from oracle import vae as ov
+    assert sum(math.prod(v) for v in ov.param_shapes(ov.SD15_VAE).values()) == 83_653_863
+    cfg = ov.VAEConfig(block_out_channels=(16, 32, 32), layers_per_block=1, groups=4, sample_size=16)
+    p = ov.init_params(cfg, seed=0)
+    x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(0))
+    z, mean, logvar = ov.encode(p, cfg, x, noise=torch.ones(2, 4, 4, 4))
+    assert z.shape == (2, 4, 4, 4) and torch.allclose(z, mean + torch.exp(0.5 * logvar))
+    assert torch.equal(ov.encode(p, cfg, x)[0], mean)                      # no noise -> posterior mean
+    img = ov.decode(p, cfg, z)
+    assert img.shape == (2, 3, 16, 16) and torch.isfinite(img).all()
+    # batch independence (GroupNorm is per sample): decoding sample 0 alone gives the same image
+    torch.testing.assert_close(ov.decode(p, cfg, z[:1]), img[:1], rtol=1e-3, atol=1e-4)
