@@ -282,18 +282,47 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
       fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(dKp + (long)k1 * a.C, a.C, rdK, tid);
       fetch_t<D>(VTp + k1, a.L, rVT, tid); fetch_t<D>(dVTp + k1, a.L, rdVT, tid);
     }
+    // Fragment reads run one step ahead of their MFMAs (explicit software pipeline; the compiler otherwise sinks every
+    // ds_read to just before its use and each MFMA group waits out the LDS latency): the second-stage V^T / dV^T
+    // fragments of a 32-key block are issued before its score MFMAs, the next block's K / dK fragments before the softmax.
+    constexpr bool PIPE = D <= 40;                  // register budget: 56 more VGPRs at D = 40
+    bf16x8 kf[F::NS], dkf[F::NS];
+    auto load1 = [&](int kb) {
+#pragma unroll
+      for (int stp = 0; stp < F::NS; ++stp) {
+        kf[stp] = lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
+        dkf[stp] = lds_a_frag(sdK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
+      }
+    };
+    if constexpr (PIPE) load1(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 vf[2][F::ND], dvf[2][F::ND];
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int d = 0; d < F::ND; ++d) {
+            vf[ks][d] = lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+            dvf[ks][d] = lds_t_frag(sdVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        load1(kb);
+      }
       f32x16 s, ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = ds[r] = 0.f;
 #pragma unroll
       for (int stp = 0; stp < F::NS; ++stp) {
-        bf16x8 kf = lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
-        bf16x8 dkf = lds_a_frag(sdK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
-        s = MFMA(kf, qf[stp], s);
-        ds = MFMA(kf, dqf[stp], ds);
-        ds = MFMA(dkf, qf[stp], ds);
+        s = MFMA(kf[stp], qf[stp], s);
+        ds = MFMA(kf[stp], dqf[stp], ds);
+        ds = MFMA(dkf[stp], qf[stp], ds);
+      }
+      if constexpr (PIPE) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb == 0) load1(1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       float p[16], x[16];
 #pragma unroll
@@ -309,10 +338,12 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int d = 0; d < F::ND; ++d) {
-          bf16x8 vf = lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
-          bf16x8 dvf = lds_t_frag(sdVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
-          acc[d] = MFMA(vf, xb[ks], acc[d]);
-          acc[d] = MFMA(dvf, pb[ks], acc[d]);
+          if constexpr (!PIPE) {
+            vf[ks][d] = lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+            dvf[ks][d] = lds_t_frag(sdVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+          }
+          acc[d] = MFMA(vf[ks][d], xb[ks], acc[d]);
+          acc[d] = MFMA(dvf[ks][d], pb[ks], acc[d]);
         }
     }
   }

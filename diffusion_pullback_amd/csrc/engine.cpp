@@ -911,6 +911,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_splitk")) splitk = value;
   else if (!strcmp(key, "gemm_kch")) kch = value;
   else if (!strcmp(key, "gemm_dma_auto")) { gemm_debug_dma_auto(value); return 0; }
+  else if (!strcmp(key, "gemm_order")) { gemm_debug_order(value); return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

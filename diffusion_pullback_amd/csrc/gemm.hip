@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
 }
 
 // tuning overrides (dpb_debug_set): 0 = heuristic
-static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0, g_dma_auto = 1;
+static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0, g_dma_auto = 1, g_force_order = -1;
+void gemm_debug_order(int o) { g_force_order = o; }
 void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 
@@ -531,6 +532,12 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   a.vec_ok = !(a.ldc & 7) && !(a.sC1 & 7) && !(a.sC2 & 7) && (!a.R || (!(a.ldr & 7) && !(a.sR1 & 7) && !(a.sR2 & 7))) &&
              (!a.rowbias || !(a.N & 7)) && !((uintptr_t)a.C & 15) && !((uintptr_t)a.R & 15) && !((uintptr_t)a.bias & 15);
   const int Z = a.Z1 * a.Z2;
+  {  // unique operand bytes per batch entry: the larger operand should be the one each XCD sees only 1/8 of
+    const double ua = (double)a.M * (a.gather == GATHER_NONE ? a.K : a.Cin), ub = (double)a.N * a.K;
+    static const int env_order = getenv("DPB_GEMM_ORDER") ? atoi(getenv("DPB_GEMM_ORDER")) : -1;   // tuning override
+    const int force = g_force_order >= 0 ? g_force_order : env_order;
+    a.order = force >= 0 ? force : (ub > ua ? 1 : 0);
+  }
   if (int dt = gemm_uses_dma(dtype, a)) {
     a.splitk = gemm_pick_splitk_dma(a, dt);
     if (int r = dt >= 512 ? launch_gemm_ring64(a, dt, st) : launch_gemm_dma(a, dt, st)) return r;

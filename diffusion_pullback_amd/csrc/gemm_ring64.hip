@@ -68,14 +68,23 @@ __global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs p) {
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tilesN = (p.N + BN - 1) / BN;
-  int bid = blockIdx.x;
-  {  // XCD-aware remap: hardware deals consecutive workgroups round-robin to the 8 XCDs; give each XCD a contiguous tile range
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  // ---- block -> (tile, batch, K split).  Workgroups are dealt round-robin to the 8 XCDs in dispatch order; give each XCD
+  // (= each L2) a CONTIGUOUS run of a processing order in which neighbours share an operand.  order 0 ("A-major", big
+  // activations / small weights): the N tiles of one A row panel are adjacent.  order 1 ("B-major", weight-heavy
+  // layers): all M tiles of one (N tile, K split) weight block are adjacent, so the block is fetched from HBM once
+  // instead of once per M tile and per XCD (measured 270 MB of reads for 36 MB of operands before this).
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  {
+    const int nwg = gridDim.x * gridDim.y * gridDim.z, q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (bid / tilesN) * BM, n0 = (bid % tilesN) * BN;
-  const int z1 = blockIdx.y / p.Z2, z2 = blockIdx.y % p.Z2;
+  int tm, tn;
+  if (p.order == 0) { tn = lin % tilesN; lin /= tilesN; tm = lin % tilesM; lin /= tilesM; }
+  else { tm = lin % tilesM; lin /= tilesM; tn = lin % tilesN; lin /= tilesN; }
+  const int ksplit = lin % (int)gridDim.z, zb = lin / (int)gridDim.z;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z1 = zb / p.Z2, z2 = zb % p.Z2;
   const bf16* A = (const bf16*)p.A + (long)(z1 / p.divA) * p.sA1 + (long)z2 * p.sA2;
   const bf16* B = (const bf16*)p.B + (long)(z1 / p.divB) * p.sB1 + (long)z2 * p.sB2;
   bf16* C = (bf16*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs p) {
   int kt_begin = 0, nk = nk_all;
   if (p.splitk > 1) {
     const int per = (nk_all + p.splitk - 1) / p.splitk;
-    kt_begin = blockIdx.z * per;
+    kt_begin = ksplit * per;
     nk = max(0, min(nk_all, kt_begin + per) - kt_begin);
   }
 
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs p) {
       Vec<float>::load(stage + row * SLD + c8 * 8, v);
       Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
       if (p.splitk > 1) {                           // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
-        float* sp = p.slab + ((long)blockIdx.z * gridDim.y + blockIdx.y) * (long)p.M * p.N + (long)m * p.N + n;
+        float* sp = p.slab + ((long)ksplit * gridDim.y + zb) * (long)p.M * p.N + (long)m * p.N + n;
         if (n + 8 <= p.N && !(p.N & 3)) {
           Vec<float>::store(sp, v);
           Vec<float>::store(sp + 4, v + 4);

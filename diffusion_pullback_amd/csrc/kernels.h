@@ -34,6 +34,7 @@ struct GemmArgs {
   float* slab = nullptr; size_t slab_bytes = 0;
   const void* zeros = nullptr;        // >= 16 zero bytes in device memory (DMA kernel reads it for padding / out-of-range rows)
   int splitk = 1, vec_ok = 0;
+  int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 int gemm_uses_big_tile(int dtype, const GemmArgs& a);
@@ -43,6 +44,7 @@ int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st);   // bf16, sin
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st);   // BK = 64 ring (gemm_ring64.hip); tile 512 | 513 | 514 | 515
 int gemm_uses_dma(int dtype, const GemmArgs& a);   // 0 = register-staged kernel, else the tile code for launch_gemm_dma
 void gemm_debug_dma_auto(int on);
+void gemm_debug_order(int o);   // -1 heuristic, 0 A-major, 1 B-major
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
 
 // ---------------------------------------------------------------- normalisation
