@@ -131,12 +131,16 @@ int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int6
 /* Introspection used by tests / bench: number of kernel launches and algorithmic GEMM flops of the last pass. */
 int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes);
 /* Measurement aid (bench.py roofline leg, never on in a timed region): bracket every GEMM launch with HIP
- * events on the engine's stream; _read synchronises and sums launches of the 128x128 (big_tile=1) or 64x64
- * (big_tile=0) instantiation: count, total milliseconds, algorithmic flops. */
+ * events on the engine's stream; _read synchronises and sums the launches of one GEMM kernel kind: count, total
+ * milliseconds, algorithmic flops.  kind: 0 register-staged 64x64, 1 register-staged 128x128, 2 BK=32 ring 128x128 /
+ * 256x128, 3 BK=32 ring 64x64, 4 BK=64 ring (gemm_ring64.hip).  _dump writes one CSV line per recorded launch. */
 int dpb_engine_profile(dpb_engine* e, int enable);
-int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double* total_ms, double* flops);
+int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
-int dpb_debug_set(const char* key, int value);   /* tuning overrides for micro-benchmarks: "gemm_tile" (0|64|128), "gemm_splitk" (0|n) */   /* one line per recorded GEMM launch */
+/* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
+ * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..515: BK=64 rings), "gemm_splitk" (n),
+ * "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block order per XCD). */
+int dpb_debug_set(const char* key, int value);
 
 #ifdef __cplusplus
 }
