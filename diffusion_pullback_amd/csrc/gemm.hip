@@ -438,7 +438,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (g_force_tile == 257) return 256;
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
-  if (g_force_tile >= 512 && g_force_tile <= 515) return g_force_tile;
+  if (g_force_tile >= 512 && g_force_tile <= 517) return g_force_tile;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
@@ -459,7 +459,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
   const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256 || tile >= 512) ? 128 : 64;
-  const int TMm = (tile == 256 || tile == 513) ? 256 : T;
+  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517) ? 256 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;

@@ -55,14 +55,15 @@ __device__ inline void wait_dma(int stages_in_flight) {   // s_waitcnt vmcnt(sta
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int S, int GATHER>
-__global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs p) {
+template <int BM, int BN, int S, int GATHER, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   constexpr int BK = 64, CH = 8, KK = BK / 16;
-  constexpr int NIA = BM / 32, NIB = BN / 32, U = NIA + NIB;          // DMA wave-instructions per stage per wave
+  constexpr int NIA = BM / (8 * WAVES), NIB = BN / (8 * WAVES), U = NIA + NIB;   // DMA wave-instructions (8 rows each) per stage per wave
+  static_assert(NIA >= 1 && NIB >= 1 && BM % (8 * WAVES) == 0 && BN % (8 * WAVES) == 0, "tile too small for the wave count");
   constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, SLD = WN + 4;
+  constexpr int WM = BM / (WAVES / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32, SLD = WN + 4;   // wave grid (WAVES/2) x 2
   constexpr int NR = TM + TN;                                          // fragment reads per K16 substep
-  constexpr int SMEM_BYTES = S * STAGE > 4 * 32 * SLD * 4 ? S * STAGE : 4 * 32 * SLD * 4;
+  constexpr int SMEM_BYTES = S * STAGE > WAVES * 32 * SLD * 4 ? S * STAGE : WAVES * 32 * SLD * 4;
   static_assert(S >= 2 && S <= 5, "ring depth");
   __shared__ __attribute__((aligned(128))) char smem[SMEM_BYTES];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
@@ -331,22 +332,25 @@ __global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int WAVES = 4>
 static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
-    case GATHER_NONE: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE>), grid, dim3(256), 0, st, a); break;
-    case GATHER_CONV: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONV>), grid, dim3(256), 0, st, a); break;
-    case GATHER_CONVT: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONVT>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_UPCONV>), grid, dim3(256), 0, st, a); break;
+    case GATHER_NONE: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
+    case GATHER_CONV: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONV, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
+    case GATHER_CONVT: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONVT, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_UPCONV, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
   }
 }
 
-// tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU)
+// tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),
+// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB)
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   const int Z = a.Z1 * a.Z2;
   auto tiles = [&](int bm, int bn) { return dim3(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn), Z, sk); };
   if (tile == 513) launch_ring64_t<256, 128, 3>(a, tiles(256, 128), st);
+  else if (tile == 516) launch_ring64_t<256, 128, 3, 8>(a, tiles(256, 128), st);
+  else if (tile == 517) launch_ring64_t<256, 128, 2, 8>(a, tiles(256, 128), st);
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);
   else launch_ring64_t<128, 128, 3>(a, tiles(128, 128), st);
