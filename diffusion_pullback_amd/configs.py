@@ -312,3 +312,61 @@ def vae_init_params(cfg: VAEConfig, seed: int = 0, gain: float = 1.0, dtype=torc
             t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
         p[name] = t.to(dtype)
     return p
+
+
+# =================================================================== SD prompt encoder (CLIP ViT-L/14 text model)
+@dataclass(frozen=True)
+class CLIPTextConfig:
+    """transformers CLIPTextModel as shipped with runwayml/stable-diffusion-v1-5 (text_encoder/config.json) -- the object
+    behind ``pipe._encode_prompt`` at reference src/modules/edit.py:505-522 (last_hidden_state of the 77 padded tokens)."""
+    vocab_size: int = 49408
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    intermediate: int = 3072
+    max_position: int = 77
+    eps: float = 1e-5
+
+
+SD15_CLIP = CLIPTextConfig()
+
+
+def clip_param_shapes(cfg: CLIPTextConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    h = cfg.hidden
+
+    def lin(n, ci, co):
+        s[n + ".weight"] = (co, ci); s[n + ".bias"] = (co,)
+
+    def norm(n):
+        s[n + ".weight"] = (h,); s[n + ".bias"] = (h,)
+
+    s["text_model.embeddings.token_embedding.weight"] = (cfg.vocab_size, h)
+    s["text_model.embeddings.position_embedding.weight"] = (cfg.max_position, h)
+    for i in range(cfg.layers):
+        pre = f"text_model.encoder.layers.{i}"
+        norm(pre + ".layer_norm1")
+        for q in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(f"{pre}.self_attn.{q}", h, h)
+        norm(pre + ".layer_norm2")
+        lin(pre + ".mlp.fc1", h, cfg.intermediate)
+        lin(pre + ".mlp.fc2", cfg.intermediate, h)
+    norm("text_model.final_layer_norm")
+    return s
+
+
+def clip_init_params(cfg: CLIPTextConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32) -> Params:
+    """Seeded synthetic weights at the exact architecture shapes (CPU generator)."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shp in clip_param_shapes(cfg).items():
+        if "embedding" in name:
+            t = 0.02 * torch.randn(shp, generator=g)
+        elif name.endswith(".weight") and len(shp) == 1:
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g)
+        else:
+            t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
+        p[name] = t.to(dtype)
+    return p

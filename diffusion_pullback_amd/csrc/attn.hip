@@ -11,11 +11,13 @@
 namespace dpb {
 
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(T* S, long nrows, int Lk, int ld) {
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(T* S, long nrows, int Lk_all, int ld, int causal_Lq) {
   constexpr int CH = TT<T>::CH;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
+  // causal (text-encoder) attention: query i = row % Lq sees keys 0..i; the masked probabilities are stored as exact zeros
+  const int Lk = causal_Lq ? min(Lk_all, (int)(row % causal_Lq) + 1) : Lk_all;
   T* sp = S + row * ld;
   const int nch = ld / CH;
   float x[NCH][CH];
@@ -144,23 +146,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, T* out, int
 }
 
 template <typename T>
-static int pick_fwd(T* S, long nrows, int Lk, int ld, hipStream_t st) {
+static int pick_fwd(T* S, long nrows, int Lk, int ld, int causal_Lq, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
   int need = (ld / CH + 63) / 64;
   dim3 grid((unsigned)((nrows + 3) / 4)), blk(256);
-  if (need <= 1) hipLaunchKernelGGL((softmax_fwd_kernel<T, 1>), grid, blk, 0, st, S, nrows, Lk, ld);
-  else if (need <= 2) hipLaunchKernelGGL((softmax_fwd_kernel<T, 2>), grid, blk, 0, st, S, nrows, Lk, ld);
-  else if (need <= 4) hipLaunchKernelGGL((softmax_fwd_kernel<T, 4>), grid, blk, 0, st, S, nrows, Lk, ld);
-  else if (need <= 8) hipLaunchKernelGGL((softmax_fwd_kernel<T, 8>), grid, blk, 0, st, S, nrows, Lk, ld);
-  else if (need <= 16) hipLaunchKernelGGL((softmax_fwd_kernel<T, 16>), grid, blk, 0, st, S, nrows, Lk, ld);
+  if (need <= 1) hipLaunchKernelGGL((softmax_fwd_kernel<T, 1>), grid, blk, 0, st, S, nrows, Lk, ld, causal_Lq);
+  else if (need <= 2) hipLaunchKernelGGL((softmax_fwd_kernel<T, 2>), grid, blk, 0, st, S, nrows, Lk, ld, causal_Lq);
+  else if (need <= 4) hipLaunchKernelGGL((softmax_fwd_kernel<T, 4>), grid, blk, 0, st, S, nrows, Lk, ld, causal_Lq);
+  else if (need <= 8) hipLaunchKernelGGL((softmax_fwd_kernel<T, 8>), grid, blk, 0, st, S, nrows, Lk, ld, causal_Lq);
+  else if (need <= 16) hipLaunchKernelGGL((softmax_fwd_kernel<T, 16>), grid, blk, 0, st, S, nrows, Lk, ld, causal_Lq);
   else { set_error("softmax: row length %d too long", ld); return -1; }
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
-int launch_softmax_fwd(int dtype, void* S, long Z, int Lq, int Lk, int ld, hipStream_t st) {
+int launch_softmax_fwd(int dtype, void* S, long Z, int Lq, int Lk, int ld, int causal, hipStream_t st) {
   if (ld % (dtype == DT_F32 ? 4 : 8)) { set_error("softmax: ld=%d not chunk aligned", ld); return -1; }
-  return dtype == DT_F32 ? pick_fwd<float>((float*)S, Z * Lq, Lk, ld, st) : pick_fwd<bf16>((bf16*)S, Z * Lq, Lk, ld, st);
+  const int cq = causal ? Lq : 0;
+  return dtype == DT_F32 ? pick_fwd<float>((float*)S, Z * Lq, Lk, ld, cq, st) : pick_fwd<bf16>((bf16*)S, Z * Lq, Lk, ld, cq, st);
 }
 
 template <typename T>

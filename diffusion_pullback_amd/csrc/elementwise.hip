@@ -76,7 +76,7 @@ int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st) {
   return dtype == DT_F32 ? geglu_t<float>(mode, a, st) : geglu_t<bf16>(mode, a, st);
 }
 
-template <typename T, int OP>   // 0: silu  1: y = x  2: y += x
+template <typename T, int OP>   // 0: silu  1: y = x  2: y += x  3: quick_gelu
 __global__ __launch_bounds__(256) void unary_kernel(const T* x, T* y, long nchunks) {
   constexpr int CH = TT<T>::CH;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256) void unary_kernel(const T* x, T* y, long nchun
     if (OP == 0) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] = silu_(v[e]);
+    } else if (OP == 3) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
     } else if (OP == 2) {
       float o[CH];
       Vec<T>::load(y + i * CH, o);
@@ -102,6 +105,7 @@ static int unary_t(int op, const void* x, void* y, long n, hipStream_t st) {
   unsigned g = grid_for(nc);
   if (op == 0) hipLaunchKernelGGL((unary_kernel<T, 0>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   else if (op == 1) hipLaunchKernelGGL((unary_kernel<T, 1>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
+  else if (op == 3) hipLaunchKernelGGL((unary_kernel<T, 3>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   else hipLaunchKernelGGL((unary_kernel<T, 2>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -109,6 +113,27 @@ static int unary_t(int op, const void* x, void* y, long n, hipStream_t st) {
 int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st) {
   return dtype == DT_F32 ? unary_t<float>(0, x, y, n, st) : unary_t<bf16>(0, x, y, n, st);
 }
+int launch_quick_gelu(int dtype, const void* x, void* y, long n, hipStream_t st) {
+  return dtype == DT_F32 ? unary_t<float>(3, x, y, n, st) : unary_t<bf16>(3, x, y, n, st);
+}
+
+// token + position embedding lookup of the text encoder, written in the engine's fp32 [b][c][t] boundary layout
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* ids, const T* tok, const T* pos, float* out, int L, int C, int vocab) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  int id = ids[b * L + t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  for (int c = threadIdx.x; c < C; c += 256)
+    out[((long)b * C + c) * L + t] = TT<T>::ld(tok + (long)id * C + c) + TT<T>::ld(pos + (long)t * C + c);
+}
+int launch_embed_tokens(int dtype, const int* ids, const void* tok, const void* pos, float* out, int batch, int L, int C, int vocab, hipStream_t st) {
+  if (batch <= 0 || L <= 0 || C <= 0 || vocab <= 0) { set_error("embed_tokens: empty problem"); return -1; }
+  if (dtype == DT_F32) hipLaunchKernelGGL((embed_tokens_kernel<float>), dim3(L, batch), dim3(256), 0, st, ids, (const float*)tok, (const float*)pos, out, L, C, vocab);
+  else hipLaunchKernelGGL((embed_tokens_kernel<bf16>), dim3(L, batch), dim3(256), 0, st, ids, (const bf16*)tok, (const bf16*)pos, out, L, C, vocab);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_axpy(int dtype, const void* x, void* y, long n, int accumulate, hipStream_t st) {
   int op = accumulate ? 2 : 1;
   return dtype == DT_F32 ? unary_t<float>(op, x, y, n, st) : unary_t<bf16>(op, x, y, n, st);

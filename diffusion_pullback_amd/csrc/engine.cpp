@@ -46,6 +46,7 @@ struct Buf {
 
 struct AttnPlan {            // per attention op, persisted from the primal pass
   int heads = 0, d = 0, Lq = 0, Lk = 0, Lqp = 0, Lkp = 0;
+  bool causal = false;                             // text-encoder attention: query i sees keys <= i (materialised path only)
   bool kv_const = false, fused = false, cross = false;   // cross: constant K/V, one-launch tangent / adjoint (attn_cross_kernel)
   int oq = 0, ok = 0, ov = 0;                      // column offsets of q / k / v inside their buffers (fused QKV projection)
   size_t P = 0, PT = 0, KT = 0, VT = 0, QT = 0, stats = 0;   // offsets
@@ -378,7 +379,7 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
     e->n_launch++;
     if (int r = launch_row_stats(ws + p.P, (float*)(ws + p.stats), (long)B * H * p.Lq, p.Lk, p.Lkp, e->stream)) return r;
   }
-  if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, e->stream)) return r;
+  if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, p.causal, e->stream)) return r;
   // V^T, K^T per head ([d][Lkp], zero padded)
   if (int r = launch_transpose(e->dtype, x.V, ws + p.VT, B, H, (long)p.Lk * x.ldv, p.d, p.Lk, p.d, x.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
   if (int r = launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
@@ -553,9 +554,11 @@ int run_op(dpb_engine* e, const Op& op, int mode, int n) {
     case DPB_OP_ATTENTION:
       return mode == MODE_PRIMAL ? attn_primal(e, op, n) : mode == MODE_TANGENT ? attn_tangent(e, op, n) : attn_adjoint(e, op, n);
     case DPB_OP_SILU: {
-      if (mode != MODE_PRIMAL) return fail("SILU op is only supported on the x-independent (time embedding) path");
+      if (mode != MODE_PRIMAL) return fail("SILU / quick-GELU ops are primal only (time-embedding path, text encoder)");
       const Buf& b = e->bufs[op.d.in0];
       e->n_launch++;
+      if (op.d.ip[0] == 1)
+        return launch_quick_gelu(e->dtype, e->P(op.d.in0), e->P(op.d.out), (long)(b.kind == DPB_BUF_SHARED ? 1 : n) * b.rows * b.C, e->stream);
       return launch_silu(e->dtype, e->P(op.d.in0), e->P(op.d.out), (long)(b.kind == DPB_BUF_SHARED ? 1 : n) * b.rows * b.C, e->stream);
     }
   }
@@ -620,6 +623,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       AttnPlan p;
       p.heads = d.ip[0];
       p.oq = d.ip[1]; p.ok = d.ip[2]; p.ov = d.ip[3];
+      p.causal = d.ip[4] != 0;
       const int Cattn = e->bufs[d.out].C;
       if (p.heads < 1 || Cattn % p.heads) return bad("channels not divisible by heads", i);
       p.d = Cattn / p.heads;
@@ -665,10 +669,10 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       AttnPlan& p = e->plans[op.attn];
       const size_t H = p.heads;
       // long bf16 self-attention layers run the flash-style kernels (attn_fused.hip): no L x L object is ever stored
-      p.fused = fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN") &&
+      p.fused = !p.causal && fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN") &&
                 p.Lq >= (getenv("DPB_FUSED_ATTN_MIN_L") ? atoi(getenv("DPB_FUSED_ATTN_MIN_L")) : 256) &&      // tuning override
                 e->bufs[d.in0].C == e->bufs[d.in1].C && e->bufs[d.in0].C == e->bufs[d.in2].C;
-      p.cross = cross_attention_supported(e->dtype, p.d, p.Lq, p.Lk, p.kv_const) && !getenv("DPB_NO_CROSS_ATTN") &&
+      p.cross = !p.causal && cross_attention_supported(e->dtype, p.d, p.Lq, p.Lk, p.kv_const) && !getenv("DPB_NO_CROSS_ATTN") &&
                 e->bufs[d.in1].C == e->bufs[d.in2].C;
       if (!p.fused) p.P = take((size_t)e->maxB * H * p.Lq * p.Lkp * es);
       p.VT = take((size_t)e->maxB * H * p.d * p.Lkp * es);
@@ -860,6 +864,13 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
 int dpb_ddim_step(const float* x, const float* eps, float* out, float* x0, int64_t n, float a_t, float a_next, void* stream) {
   if (!x || !eps || !out) return fail("null argument");
   return launch_ddim_step(x, eps, out, x0, n, a_t, a_next, (hipStream_t)stream);
+}
+
+int dpb_embed_tokens(const int32_t* ids, const void* tok_table, const void* pos_table, int dtype, float* out, int batch, int tokens,
+                     int channels, int vocab, void* stream) {
+  if (!ids || !tok_table || !pos_table || !out) return fail("null argument");
+  if (dtype != DPB_F32 && dtype != DPB_BF16) return fail("bad dtype %d", dtype);
+  return launch_embed_tokens(dtype, ids, tok_table, pos_table, out, batch, tokens, channels, vocab, (hipStream_t)stream);
 }
 
 int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int64_t n, float a, float b, float c, void* stream) {

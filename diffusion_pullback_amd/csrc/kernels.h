@@ -74,7 +74,7 @@ int launch_layernorm(int dtype, int mode, const LNArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------- attention pieces
 // rows: Z * Lq rows of length ld (valid columns < Lk, the rest are written as 0)
-int launch_softmax_fwd(int dtype, void* S, long Z, int Lq, int Lk, int ld, hipStream_t st);
+int launch_softmax_fwd(int dtype, void* S, long Z, int Lq, int Lk, int ld, int causal, hipStream_t st);   // causal: query i sees keys <= i
 // dP = P o (dS - rowsum(P o dS)), in place on dS; P row index uses z_p = (z / Z2 / kps) * Z2 + z % Z2; optional D out
 int launch_softmax_jvp(int dtype, const void* P, void* dS, float* D, long Z, int Z2, int kps, int Lq, int Lk, int ld,
                        hipStream_t st);
@@ -121,6 +121,9 @@ struct GegluArgs {
 };
 int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st);
 int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st);
+int launch_quick_gelu(int dtype, const void* x, void* y, long n, hipStream_t st);   // x * sigmoid(1.702 x) (CLIP text encoder MLP)
+// out[b][c][t] = tok[ids[b][t]][c] + pos[t][c]  (fp32, the engine's NCHW boundary layout with H*W = L tokens); tables in `dtype`
+int launch_embed_tokens(int dtype, const int* ids, const void* tok, const void* pos, float* out, int batch, int L, int C, int vocab, hipStream_t st);
 int launch_axpy(int dtype, const void* x, void* y, long n, int accumulate, hipStream_t st);   // y (+)= x
 // channel concat / split on [rows][C] tensors: copy src[rows][Cs] <-> dst[rows][Cd] column window at c0
 int launch_copy_cols(int dtype, const void* src, int lds, int cs0, void* dst, int ldd, int cd0, long rows, int ncols,

@@ -54,6 +54,7 @@ SYMBOLS = {
     "dpb_pullback_iterate": (_I, [_P, _I, _P, _P, _P, _P, _I, _I]),
     "dpb_ddim_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
     "dpb_lincomb": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _P]),
+    "dpb_embed_tokens": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "dpb_engine_stats": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dpb_engine_profile": (_I, [_P, _I]),
     "dpb_debug_set": (_I, [C.c_char_p, _I]),

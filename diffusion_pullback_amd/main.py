@@ -8,7 +8,8 @@ constants of main.py:30-34 (op='mid', block_idx=0, vis_num=4, vis_num_pc=2, pca_
 Flags of the reference's dead experiments are accepted and ignored with a note.
 New flags (not in the reference): --pca_rank, --op, --block_idx, --dtype bf16, --weights (state-dict
 file; default: seeded synthetic weights, there are no checkpoints offline), --net_scale (reduced nets),
---vae (none | synthetic | <state-dict file>: decode the edited latents to PNGs with the on-device AutoencoderKL).
+--vae (none | synthetic | <state-dict file>: decode the edited latents to PNGs with the on-device AutoencoderKL),
+--text_encoder (none | synthetic | <state-dict file>) + --tokenizer_dir (CLIP vocab.json / merges.txt): on-device prompt encoder.
 """
 from __future__ import annotations
 
@@ -53,7 +54,7 @@ _FLAGS = [  # (name, type, default) -- define_argparser.py:20-110, live path onl
     ("run_edit_local_encoder_pullback_zt", str2bool, False),
     # new
     ("pca_rank", int, 2), ("op", str, "mid"), ("block_idx", int, 0), ("vis_num", int, 4), ("vis_num_pc", int, 2), ("weights", str, ""),
-    ("net_scale", str, "full"), ("vae", str, "none"),
+    ("net_scale", str, "full"), ("vae", str, "none"), ("text_encoder", str, "none"), ("tokenizer_dir", str, ""),
 ]
 
 
@@ -136,12 +137,30 @@ def build_vae(args):
     return AutoencoderKL(cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=1)
 
 
+def build_prompt_encoder(args):
+    """``pipe._encode_prompt`` of the reference (edit.py:505-522) on the HIP engine; None keeps the seeded stand-in
+    embeddings.  The BPE tokenizer needs CLIP's vocabulary files (``--tokenizer_dir``, loaded with transformers'
+    CLIPTokenizer); without them a byte-level stand-in tokenizer is used, which is only meaningful with synthetic weights."""
+    if args.text_encoder == "none" or not args.is_stable_diffusion or args.net_scale != "full":
+        return None
+    from .text_encoder import ClipTextEncoder
+    cfg = cf.SD15_CLIP
+    if args.tokenizer_dir:
+        from transformers import CLIPTokenizer
+        tk = CLIPTokenizer.from_pretrained(args.tokenizer_dir)
+        tokenizer = lambda s: tk(s, padding="max_length", max_length=cfg.max_position, truncation=True).input_ids
+    else:
+        tokenizer = lambda s: ([cfg.vocab_size - 2] + [256 + b for b in s.encode()][: cfg.max_position - 2] + [cfg.vocab_size - 1] * cfg.max_position)[: cfg.max_position]
+    params = cf.clip_init_params(cfg, seed=args.seed) if args.text_encoder == "synthetic" else torch.load(args.text_encoder, map_location="cpu")
+    return ClipTextEncoder(cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=1, tokenizer=tokenizer).encode_prompt
+
+
 def main(argv=None):
     args = preset(parse_args(argv))
     unet = build_unet(args)
     if args.is_stable_diffusion:
         print("is stable-diffusion")
-        edit = EditStableDiffusion(args, unet=unet, vae=build_vae(args))
+        edit = EditStableDiffusion(args, unet=unet, vae=build_vae(args), prompt_encoder=build_prompt_encoder(args))
     else:
         print("is NOT stable-diffusion")
         edit = EditUncondDiffusion(args, unet=unet)

@@ -119,12 +119,12 @@ class Tape:
                  w=[self._dev(self.p[name + ".weight"], torch.float32), self._dev(self.p[name + ".bias"], torch.float32), 0, 0])
         return out
 
-    def attention(self, q: int, k: int, v: int, heads: int, c: int = 0, offsets=(0, 0, 0)) -> int:
+    def attention(self, q: int, k: int, v: int, heads: int, c: int = 0, offsets=(0, 0, 0), causal: bool = False) -> int:
         """q / k / v may be column windows (``offsets``) of wider buffers, e.g. one fused [rows][3C] projection."""
         rows, cq, _ = self.buffers[q]
         c = c or cq
         out = self.buf(rows, c)
-        self._op(kind=L.OP_ATTENTION, in0=q, in1=k, in2=v, out=out, ip=[heads, offsets[0], offsets[1], offsets[2]] + [0] * 8)
+        self._op(kind=L.OP_ATTENTION, in0=q, in1=k, in2=v, out=out, ip=[heads, offsets[0], offsets[1], offsets[2], int(causal)] + [0] * 7)
         return out
 
     def geglu(self, x: int) -> int:
@@ -137,6 +137,13 @@ class Tape:
         rows, c, kind = self.buffers[x]
         out = self.buf(rows, c, kind)
         self._op(kind=L.OP_SILU, in0=x, out=out)
+        return out
+
+    def quick_gelu(self, x: int) -> int:
+        """x * sigmoid(1.702 x) (CLIP MLP activation); primal only."""
+        rows, c, kind = self.buffers[x]
+        out = self.buf(rows, c, kind)
+        self._op(kind=L.OP_SILU, in0=x, out=out, ip=[1] + [0] * 11)
         return out
 
     def concat(self, a: int, b: int) -> int:
@@ -383,4 +390,28 @@ def build_vae_decoder(cfg, params, dtype, device) -> Tape:
     n = t.groupnorm("decoder.conv_norm_out", h, cfg.groups, cfg.gn_eps, True)
     o = t.conv("decoder.conv_out", n, (r, r), cfg.out_channels, need_adj=False)
     t.tap("image", o, cfg.out_channels, r, r)
+    return t
+
+
+# =================================================================== SD prompt encoder (primal only)
+def build_clip_text(cfg, params, dtype, device) -> Tape:
+    """[tokens][hidden] token+position embeddings (dpb_embed_tokens) -> last_hidden_state [tokens][hidden]:
+    transformers CLIPTextModel (pre-LN transformer, causal self-attention, quick-GELU MLP, final LayerNorm), the
+    text_encoder behind ``pipe._encode_prompt`` (reference src/modules/edit.py:505-522).  cfg: configs.CLIPTextConfig."""
+    t = Tape(params, dtype, device)
+    n, h = cfg.max_position, cfg.hidden
+    t.temb_in = t.buf(1, 8, L.BUF_SHARED)          # no time embedding; the engine wants the slot
+    t.x = t.buf(n, h)
+    x = t.x
+    for i in range(cfg.layers):
+        pre = f"text_model.encoder.layers.{i}"
+        z = t.layernorm(pre + ".layer_norm1", x, cfg.eps)
+        qkv = t.conv((pre + ".self_attn.q_proj", pre + ".self_attn.k_proj", pre + ".self_attn.v_proj"), z, (n, 1), 3 * h, ks=1, need_adj=False)
+        a = t.attention(qkv, qkv, qkv, cfg.heads, h, (0, h, 2 * h), causal=True)
+        x = t.conv(pre + ".self_attn.out_proj", a, (n, 1), h, ks=1, res=x, need_adj=False)
+        z = t.layernorm(pre + ".layer_norm2", x, cfg.eps)
+        f = t.quick_gelu(t.conv(pre + ".mlp.fc1", z, (n, 1), cfg.intermediate, ks=1, need_adj=False))
+        x = t.conv(pre + ".mlp.fc2", f, (n, 1), h, ks=1, res=x, need_adj=False)
+    o = t.layernorm("text_model.final_layer_norm", x, cfg.eps)
+    t.tap("last_hidden_state", o, h, n, 1)
     return t

@@ -81,3 +81,17 @@ def test_tape_structure_vae_and_cli_default():
                                   "--x_space_guidance_scale", "1", "--x_space_guidance_num_step", "4", "--edit_t", "0.7",
                                   "--run_edit_local_encoder_pullback_zt", "True"]))
     assert args.vae == "none" and M.build_vae(args) is None
+    assert args.text_encoder == "none" and M.build_prompt_encoder(args) is None
+
+
+def test_tape_structure_clip_text():
+    """Prompt-encoder tape: causal attention ops, quick-GELU ops, primal-only weights."""
+    from diffusion_pullback_amd import configs as cf
+    from diffusion_pullback_amd.tape import build_clip_text
+    cfg = cf.CLIPTextConfig(vocab_size=50, hidden=16, layers=2, heads=2, intermediate=32, max_position=8)
+    t = build_clip_text(cfg, cf.clip_init_params(cfg), torch.bfloat16, "cpu")
+    att = [o for o in t.ops if o["kind"] == 4]
+    assert len(att) == 2 and all(o["ip"][0] == 2 and o["ip"][4] == 1 for o in att)                 # heads, causal flag
+    assert sum(1 for o in t.ops if o["kind"] == 6 and o["ip"][0] == 1) == 2                           # quick-GELU
+    assert t.tap_shape[t.taps["last_hidden_state"]] == (16, 8, 1) and t.buffers[t.x][:2] == (8, 16)
+    assert all(o["w"][1] == 0 for o in t.ops if o["kind"] == 1)

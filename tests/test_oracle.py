@@ -115,3 +115,20 @@ def test_vae_oracle_shapes_and_param_count():
     assert img.shape == (2, 3, 16, 16) and torch.isfinite(img).all()
     # batch independence (GroupNorm is per sample): decoding sample 0 alone gives the same image
     torch.testing.assert_close(ov.decode(p, cfg, z[:1]), img[:1], rtol=1e-3, atol=1e-4)
+
+
+def test_clip_text_oracle_param_count_and_causality():
+    """CLIP ViT-L/14 text model restatement (PARITY UNPINNED, transformers weights absent): published parameter count and the
+    causal-mask property of the encoder behind pipe._encode_prompt (reference src/modules/edit.py:505-522)."""
+    import math
+    from oracle import clip_text as oc
+    assert sum(math.prod(v) for v in oc.param_shapes(oc.SD15_CLIP).values()) == 123_060_480
+    cfg = oc.CLIPTextConfig(vocab_size=50, hidden=16, layers=2, heads=2, intermediate=32, max_position=8)
+    p = oc.init_params(cfg, seed=0)
+    ids = torch.randint(0, 50, (2, 8), generator=torch.Generator().manual_seed(0))
+    y = oc.encode(p, cfg, ids)
+    ids2 = ids.clone(); ids2[:, 5:] = (ids2[:, 5:] + 3) % 50
+    y2 = oc.encode(p, cfg, ids2)
+    assert y.shape == (2, 8, 16)
+    torch.testing.assert_close(y2[:, :5], y[:, :5], rtol=1e-5, atol=1e-6)
+    assert not torch.allclose(y2[:, 5:], y[:, 5:], atol=1e-3)
