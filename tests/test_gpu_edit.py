@@ -114,3 +114,32 @@ def test_sd_driver_end_to_end(tmp_path):
     d = os.path.join(a.input_root, "local_encoder_pullback_stable_diffusion-dataset_Examples-num_steps_20-pca_rank_2")
     assert os.path.exists(os.path.join(d, 'vT-local_basis-Examples_5-0.7T-"tiger"-mid-block_0-seed_0.pt'))
     assert torch.isfinite(res[0]).all()
+
+
+def test_sd_driver_with_on_device_vae_and_prompt_encoder(tmp_path):
+    """Row f4: the edit driver with the HIP AutoencoderKL (decoded PNGs instead of latents) and an injected on-device prompt
+    encoder (reference src/modules/edit.py:476-480, :505-522) at reduced network sizes."""
+    from diffusion_pullback_amd import configs as cf
+    from diffusion_pullback_amd import main as m
+    from diffusion_pullback_amd.edit import EditStableDiffusion
+    from diffusion_pullback_amd.text_encoder import ClipTextEncoder
+    argv = ["--note", "t", "--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Examples", "--result_folder", str(tmp_path),
+            "--device", DEV, "--edit_prompt", "sitting dog", "--x_space_guidance_scale", "1", "--x_space_guidance_num_step", "4",
+            "--edit_t", "0.7", "--for_steps", "10", "--inv_steps", "10", "--net_scale", "small", "--pca_rank", "2", "--dtype", "bf16",
+            "--run_edit_local_encoder_pullback_zt", "False", "--vae", "synthetic"]
+    a = m.preset(m.parse_args(argv))
+    a.input_root = os.path.join(str(tmp_path), "inputs")
+    unet = m.build_unet(a)
+    vae = m.build_vae(a)
+    assert vae is not None and vae.cfg.latent_size == a.image_size
+    ccfg = cf.CLIPTextConfig(vocab_size=300, hidden=64, layers=2, heads=4, intermediate=128, max_position=77)       # cross_dim of the small U-Net
+    tok = lambda s: ([298] + [b % 256 for b in s.encode()][:75] + [299] * 77)[:77]
+    enc = ClipTextEncoder(ccfg, cf.clip_init_params(ccfg, seed=1), dtype=torch.bfloat16, device=DEV, max_batch=1, tokenizer=tok)
+    ed = EditStableDiffusion(a, unet=unet, vae=vae, prompt_encoder=enc.encode_prompt)
+    assert ed.edit_prompt_emb.shape == (1, 77, 64) and torch.isfinite(ed.edit_prompt_emb).all()
+    ed.run_edit_local_encoder_pullback_zt(idx=5, op="mid", block_idx=0, vis_num=4, vis_num_pc=1, pca_rank=2, edit_prompt="tiger")
+    pngs = [f for f in os.listdir(ed.result_folder) if f.endswith(".png")]
+    assert len(pngs) >= 2, pngs                                         # x0_gen-*_pos / _neg decoded by the HIP autoencoder
+    from PIL import Image
+    im = Image.open(os.path.join(ed.result_folder, sorted(pngs)[0]))
+    assert im.size[1] == 2 * a.image_size                               # small VAE: 2x upsampling of the 16x16 latents
