@@ -41,7 +41,7 @@ static inline int round8(int v) { return (v + 7) / 8 * 8; }
 struct Buf {
   int rows = 0, C = 0, kind = 0, Cv = 0;   // Cv: valid (un-padded) channels
   bool is_const = true;      // independent of x
-  size_t p_off = 0, t_off = 0, g_off = 0;
+  size_t p_off = 0, t_off = 0, g_off = 0, g_off0 = 0;   // g_off0: planned cotangent storage (g_off may be swapped within an adjoint pass)
 };
 
 struct AttnPlan {            // per attention op, persisted from the primal pass
@@ -210,8 +210,15 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
     e->ginit[d.in0] = 1;
   }
   if (d.res >= 0 && !e->bufs[d.res].is_const) {
-    e->n_launch++;
-    if (int r = launch_axpy(e->dtype, e->G(d.out), e->G(d.res), (long)n * bo.rows * bo.C, e->ginit[d.res], e->stream)) return r;
+    Buf& br = e->bufs[d.res];
+    if (!e->ginit[d.res] && br.rows == bo.rows && br.C == bo.C && br.kind == bo.kind) {
+      // first cotangent of the residual stream: G(out) is dead once its producer (this op) has run, so hand its storage
+      // over instead of copying it (38 copies of up to 13 MB per adjoint pass on SD-1.5); dpb_vjp restores the plan
+      std::swap(br.g_off, e->bufs[d.out].g_off);
+    } else {
+      e->n_launch++;
+      if (int r = launch_axpy(e->dtype, e->G(d.out), e->G(d.res), (long)n * bo.rows * bo.C, e->ginit[d.res], e->stream)) return r;
+    }
     e->ginit[d.res] = 1;
   }
   return 0;
@@ -661,7 +668,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   for (auto& b : e->bufs)
     if (!b.is_const) b.t_off = take((size_t)e->maxT * b.rows * b.C * es);
   for (auto& b : e->bufs)
-    if (!b.is_const) b.g_off = take((size_t)e->maxT * b.rows * b.C * es);
+    if (!b.is_const) b.g_off = b.g_off0 = take((size_t)e->maxT * b.rows * b.C * es);
   size_t s1 = 0, s2 = 0, t1 = 0, dv = 0, ctmp = 0, maxrc = 0;
   for (auto& op : e->ops) {
     const dpb_op_desc& d = op.d;
@@ -814,6 +821,7 @@ int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   e->n_launch = 0; e->flops = 0; e->gbytes = 0;
   const Buf& bt = e->bufs[tap];
   std::fill(e->ginit.begin(), e->ginit.end(), 0);
+  for (auto& b : e->bufs) b.g_off = b.g_off0;
   e->n_launch++;
   if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
   e->ginit[tap] = 1;
