@@ -44,50 +44,50 @@ template <int D> struct FA {
 // Register-staged tile loads: fetch() issues the global loads of the NEXT stage before the MFMAs of the current one,
 // commit() writes them to LDS after the barrier, so HBM/L2 latency overlaps the compute.
 // Row tile: [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled.
-template <int D> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + FA<D>::NT - 1) / FA<D>::NT]; };
-template <int D>
-__device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<D>& rg, int tid) {
+template <int D, int NTH = FA<D>::NT> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + NTH - 1) / NTH]; };
+template <int D, int NTH = FA<D>::NT>
+__device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<D, NTH>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + F::NT - 1) / F::NT;
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + NTH - 1) / NTH;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * F::NT;
+    const int c = tid + i * NTH;
     const int r = c / CPR, cc = (c % CPR) * 8;
     rg.v[i] = make_uint4(0, 0, 0, 0);
     if (c < F::BI * CPR && cc < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
   }
 }
-template <int D>
-__device__ inline void commit_row(const RowRegs<D>& rg, bf16* lds, int tid) {
+template <int D, int NTH = FA<D>::NT>
+__device__ inline void commit_row(const RowRegs<D, NTH>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + F::NT - 1) / F::NT;
+  constexpr int CPR = F::DP / 8, N = (F::BI * CPR + NTH - 1) / NTH;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * F::NT;
+    const int c = tid + i * NTH;
     if (c < F::BI * CPR) *reinterpret_cast<uint4*>(lds + (c / CPR) * F::LDR + (c % CPR) * 8) = rg.v[i];
   }
 }
 // T tile: [D rows][BI cols] sub-matrix of a transposed copy (row stride gs) -> LDS [DO][LDT], rows D..DO zero filled.
-template <int D> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + FA<D>::NT - 1) / FA<D>::NT]; };
-template <int D>
-__device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D>& rg, int tid) {
+template <int D, int NTH = FA<D>::NT> struct TRegs { uint4 v[(FA<D>::DO * (FA<D>::BI / 8) + NTH - 1) / NTH]; };
+template <int D, int NTH = FA<D>::NT>
+__device__ inline void fetch_t(const bf16* __restrict__ src, long gs, TRegs<D, NTH>& rg, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + F::NT - 1) / F::NT;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + NTH - 1) / NTH;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * F::NT;
+    const int c = tid + i * NTH;
     const int r = c / CPR, cc = (c % CPR) * 8;
     rg.v[i] = make_uint4(0, 0, 0, 0);
     if (c < F::DO * CPR && r < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
   }
 }
-template <int D>
-__device__ inline void commit_t(const TRegs<D>& rg, bf16* lds, int tid) {
+template <int D, int NTH = FA<D>::NT>
+__device__ inline void commit_t(const TRegs<D, NTH>& rg, bf16* lds, int tid) {
   using F = FA<D>;
-  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + F::NT - 1) / F::NT;
+  constexpr int CPR = F::BI / 8, N = (F::DO * CPR + NTH - 1) / NTH;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int c = tid + i * F::NT;
+    const int c = tid + i * NTH;
     if (c < F::DO * CPR) {                      // rows are 8-byte (not 16-byte) aligned: two ds_write_b64
       bf16* dst = lds + (c / CPR) * F::LDT + (c % CPR) * 8;
       *reinterpret_cast<uint2*>(dst) = make_uint2(rg.v[i].x, rg.v[i].y);
@@ -462,6 +462,139 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ adjoint, query-major, all cotangents of a sample in one block
+// The probabilities P depend on the primal sample only, yet every (cotangent, head) block of the kernel above recomputes
+// S = Q K^T and exp() for them.  Here one block owns 128 queries of one (sample, head) and carries up to TJ cotangents:
+// S and P once per tile, then per cotangent gP_t = gO_t V^T, gS_t = P o (gP_t - D_t), gQ_t += gS_t K.  Per 64-key tile and
+// wave: 6 + 14*TJ MFMAs instead of 20*TJ, 10 LDS fragment reads instead of 20*TJ, 32 exp instead of 32*TJ; the TJ
+// independent cotangent streams give the scheduler MFMA work to overlap with each other's softmax arithmetic.
+// 4 waves (one per SIMD, up to 512 registers each: TJ*ND accumulators + TJ*NS cotangent fragments stay in registers).
+template <int D, int TJ>
+__global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
+  using F = FA<D>;
+  constexpr int NTH = 256;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
+  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int ngrp = (a.kps + TJ - 1) / TJ;
+  const int grp = blockIdx.y % ngrp, bh = blockIdx.y / ngrp, b = bh / a.H, h = bh % a.H;
+  const int j0 = b * a.kps + grp * TJ, nj = min(TJ, a.kps - grp * TJ);
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const long LC = (long)a.L * a.C, LCo = (long)a.L * a.Co;
+  const bf16* Kp = a.K + b * LC + h * D;
+  const bf16* Vp = a.V + b * LC + h * D;
+  const bf16* KTp = a.KT + ((long)b * a.H + h) * D * a.L;
+  bf16x8 qf[F::NS], gof[TJ][F::NS];
+  load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
+  float Dq[TJ];
+  {
+    bf16x8 of[F::NS];
+    load_outer_frags<D>(a.O + b * LCo + (long)q * a.Co + h * D, of, lhi);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      Dq[t] = 0.f;
+      if (t < nj) {
+        load_outer_frags<D>(a.gO + (long)(j0 + t) * LCo + (long)q * a.Co + h * D, gof[t], lhi);
+#pragma unroll
+        for (int stp = 0; stp < F::NS; ++stp) {
+          const unsigned short* g16 = reinterpret_cast<const unsigned short*>(&gof[t][stp]);
+          const unsigned short* o16 = reinterpret_cast<const unsigned short*>(&of[stp]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) Dq[t] += bf2f(g16[e]) * bf2f(o16[e]);
+        }
+        Dq[t] += __shfl_xor(Dq[t], 32, 64);
+      } else {
+#pragma unroll
+        for (int stp = 0; stp < F::NS; ++stp) gof[t][stp] = bf16x8{};
+      }
+    }
+  }
+  const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
+  const float c2 = a.scale * 1.44269504088896f;
+  const float m2 = st[0] * 1.44269504088896f, il = st[1];
+  f32x16 acc[TJ][F::ND];
+#pragma unroll
+  for (int t = 0; t < TJ; ++t)
+#pragma unroll
+    for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][d][r] = 0.f;
+  RowRegs<D, NTH> rK, rV;
+  TRegs<D, NTH> rKT;
+  fetch_row<D, NTH>(Kp, a.C, rK, tid); fetch_row<D, NTH>(Vp, a.C, rV, tid); fetch_t<D, NTH>(KTp, a.L, rKT, tid);
+  for (int k0 = 0; k0 < a.L; k0 += F::BI) {
+    __syncthreads();
+    commit_row<D, NTH>(rK, sK, tid); commit_row<D, NTH>(rV, sV, tid); commit_t<D, NTH>(rKT, sKT, tid);
+    __syncthreads();
+    if (k0 + F::BI < a.L) {
+      const int k1 = k0 + F::BI;
+      fetch_row<D, NTH>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, NTH>(Vp + (long)k1 * a.C, a.C, rV, tid);
+      fetch_t<D, NTH>(KTp + k1, a.L, rKT, tid);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 vf[F::NS], ktf[2][F::ND];
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int stp = 0; stp < F::NS; ++stp) {
+        s = MFMA(lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), qf[stp], s);
+        vf[stp] = lds_a_frag(sV, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int d = 0; d < F::ND; ++d) ktf[ks][d] = lds_t_frag(sKT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il;
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) {
+        if (t < nj) {
+          f32x16 gp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gp[r] = 0.f;
+#pragma unroll
+          for (int stp = 0; stp < F::NS; ++stp) gp = MFMA(vf[stp], gof[t][stp], gp);
+          float gs[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gs[r] = p[r] * (gp[r] - Dq[t]);
+          bf16x8 gsb[2];
+          pack_b(gs, gsb);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int d = 0; d < F::ND; ++d) acc[t][d] = MFMA(ktf[ks][d], gsb[ks], acc[t][d]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TJ; ++t) {
+    if (t >= nj) continue;
+    bf16* gQp = a.gQ + (long)(j0 + t) * LC + (long)q * a.C + h * D;
+#pragma unroll
+    for (int d = 0; d < F::ND; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = d * 32 + 8 * g + 4 * lhi;
+        if (col < D) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = a.scale * acc[t][d][g * 4 + i];
+          if (a.accQ) {
+            uint2 ov = *reinterpret_cast<const uint2*>(gQp + col);
+            v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
+            v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+          }
+          *reinterpret_cast<uint2*>(gQp + col) =
+              make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        }
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
 template <int D>
 __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
@@ -810,7 +943,13 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
   dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
-  if (f.d == 40) {
+  static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernels (tuning switch)
+  if (f.d == 40 && (multi & 1) && f.L % 128 == 0 && nt % f.kps == 0) {
+    constexpr int TJ = 5;
+    const int ngrp = (f.kps + TJ - 1) / TJ;
+    hipLaunchKernelGGL((attn_adj_q_multi_kernel<40, TJ>), dim3(f.L / 128, (nt / f.kps) * f.H * ngrp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
+  } else if (f.d == 40) {
     hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
     hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
   } else if (f.d == 80) {
