@@ -468,6 +468,9 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
 // S and P once per tile, then per cotangent gP_t = gO_t V^T, gS_t = P o (gP_t - D_t), gQ_t += gS_t K.  Per 64-key tile and
 // wave: 6 + 14*TJ MFMAs instead of 20*TJ, 10 LDS fragment reads instead of 20*TJ, 32 exp instead of 32*TJ; the TJ
 // independent cotangent streams give the scheduler MFMA work to overlap with each other's softmax arithmetic.
+// (The same construction for the tangent kernel and for the key-major adjoint needs a dK / dV^T resp. gO / gO^T tile per
+// tangent in every stage; with one 4-wave block per CU its 49 KB-per-32-keys stream is latency-bound -- measured 760-870 us
+// against 430 us for attn_jvp_kernel -- so only the query-major adjoint, whose streamed tiles are all shared, uses it.)
 // 4 waves (one per SIMD, up to 512 registers each: TJ*ND accumulators + TJ*NS cotangent fragments stay in registers).
 template <int D, int TJ>
 __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
@@ -943,7 +946,7 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
   dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
-  static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernels (tuning switch)
+  static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernel (tuning switch)
   if (f.d == 40 && (multi & 1) && f.L % 128 == 0 && nt % f.kps == 0) {
     constexpr int TJ = 5;
     const int ngrp = (f.kps + TJ - 1) / TJ;
