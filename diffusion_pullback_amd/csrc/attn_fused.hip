@@ -33,7 +33,8 @@ template <int D> struct FA {
   static constexpr int DP = NS * 16;            // padded head dim (score products)
   static constexpr int ND = (D + 31) / 32;      // 32-wide output tiles over the head dim
   static constexpr int DO = ND * 32;
-  static constexpr int BI = 64;                 // inner rows per LDS stage
+  static constexpr int BI = D <= 80 ? 128 : 64;  // inner rows per LDS stage: at 128 the one-stage-ahead register prefetch has
+                                                // twice the MFMA time to land (key-major adjoint -8 %); head dim 160 would exceed the LDS
   static constexpr int LDR = DP + 8;            // LDS stride of [row][d] tiles   (bf16 elements)
   static constexpr int LDT = BI + 4;            // LDS stride of [d][row] tiles: 68 elements = 34 dwords = 2*odd, so the 32 rows of a
                                                 // ds_read_b64 fragment read hit 32 distinct even banks (72 gave a 2-way conflict)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
       fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_t<D>(VTp + k1, a.L, rVT, tid);
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < F::BI / 32; ++kb) {
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
     };
     if constexpr (PIPE) load1(0);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < F::BI / 32; ++kb) {
       bf16x8 vf[2][F::ND], dvf[2][F::ND];
       if constexpr (PIPE) {
 #pragma unroll
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
       }
       if constexpr (PIPE) {
         __builtin_amdgcn_sched_barrier(0);
-        if (kb == 0) load1(1);
+        if (kb + 1 < F::BI / 32) load1(kb + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       float p[16], x[16];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
       fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_t<D>(KTp + k1, a.L, rKT, tid);
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < F::BI / 32; ++kb) {
       f32x16 s, gp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = gp[r] = 0.f;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
       fetch_t<D, NTH>(KTp + k1, a.L, rKT, tid);
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < F::BI / 32; ++kb) {
       bf16x8 vf[F::NS], ktf[2][F::ND];
       f32x16 s;
 #pragma unroll
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
       fetch_stats(q1);
     }
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < F::BI / 32; ++qb) {
       f32x16 s, gp;     // [query = register row][key = lane]
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = gp[r] = 0.f;
