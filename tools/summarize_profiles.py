@@ -18,12 +18,13 @@ TAG = sys.argv[3] if len(sys.argv) > 3 else "r01"
 
 
 def norm(name: str) -> str:
-    """'void dpb::gemm_ring64_kernel<128, 128, 2, 0>(dpb::GemmArgs)' -> 'gemm_ring64_kernel<128,128,2>' (the trailing
-    template argument of the GEMM kernels is the compile-time gather mode: all four share one bench label)."""
+    """'void dpb::gemm_ring64_kernel<128, 128, 2, 0, 4>(dpb::GemmArgs)' -> 'gemm_ring64_kernel<128,128,2>' (the trailing
+    template arguments of the GEMM kernels are the compile-time gather mode and wave count: they share one bench label)."""
     n = re.sub(r"\(.*$", "", name.replace("void ", "").replace("dpb::", "")).replace(" ", "")
     m = re.match(r"(gemm_kernel|gemm_dma_kernel|gemm_ring64_kernel)<(.*)>$", n)
     if m:
-        n = f"{m.group(1)}<{','.join(m.group(2).split(',')[:-1])}>"
+        keep = 3 if m.group(1) != "gemm_kernel" else 4          # tile (+ stages / K chunk); the rest is gather mode (and wave count)
+        n = f"{m.group(1)}<{','.join(m.group(2).split(',')[:keep])}>"
     return n
 
 
