@@ -193,6 +193,18 @@ def main():
                            "algorithmic_flops_per_step": 2 * k * 2 * mac * 1e9 if mac else None,
                            "whole_step_frac_of_peak": (2 * k * 2 * mac * 1e9 / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK[dname]) if mac else None}
 
+    if rank == 0 and not a.no_roofline and S == 1:
+        # ---- time to a converged basis under the reference's own stop rule (utils.py:803-808: allclose(V_prev, V, atol=1e-3) and
+        # i > min_iter=10, at most 100 iterations), host loop with one 8-byte read-back per iteration; not part of `value`
+        torch.cuda.synchronize(dev); tc = time.perf_counter()
+        if a.workload == "ddpm256":
+            net.local_encoder_pullback_xt(x=xs[0:1], t=t, op=tap[0], block_idx=tap[1], pca_rank=k, V0=V0)
+        else:
+            net.local_encoder_pullback_zt(sample=xs[0:1], timestep=t, encoder_hidden_states=ctx, op=tap[0], block_idx=tap[1], pca_rank=k, V0=V0)
+        torch.cuda.synchronize(dev)
+        res["time_to_converged_basis"] = {"ms": 1e3 * (time.perf_counter() - tc), "iters": net.last_iters, "final_dist": net.last_dist,
+                                          "rule": "reference stop rule: allclose(V_prev, V, atol=1e-3) and i > 10, max_iter 100"}
+
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference) on the host cores
         from oracle import pullback as opb

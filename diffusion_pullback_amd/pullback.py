@@ -117,6 +117,7 @@ class PullbackUNet:
                 if self.verbose:
                     print("reach convergence threshold : ", dist)
                 break
+        self.last_iters, self.last_dist = i + 1, dist          # introspection for bench.py's time-to-converged-basis leg
         if self.verbose:
             print("power method runtime ==", time.time() - time_s)
         dt = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
