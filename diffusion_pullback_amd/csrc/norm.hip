@@ -161,10 +161,9 @@ int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- LayerNorm: one wave per token row
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {
+template <typename T, int MODE, int MAXI>           // MAXI*64 >= chunks per row (C <= 1280 f32 / 2560 bf16 at MAXI = 5): sized per launch so
+__global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {   // that the 320- / 640-channel rows do not carry 80 idle registers
   constexpr int CH = TT<T>::CH;
-  constexpr int MAXI = 5;                       // up to 5*64 chunks per row (C <= 1280 f32 / 2560 bf16)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -176,12 +175,14 @@ __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {
   }
   const T* xp = (const T*)a.x + prow * a.C;
   float x[MAXI][CH];
+  float v[MAXI][CH];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     int c = lane + i * 64;
     if (c < nch) {
       Vec<T>::load(xp + c * CH, x[i]);
+      if (MODE != MODE_PRIMAL) Vec<T>::load((const T*)a.d + row * a.C + c * CH, v[i]);   // issued with x: both in flight across the reductions
 #pragma unroll
       for (int e = 0; e < CH; ++e) s += x[i][e];
     }
@@ -215,14 +216,11 @@ __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {
     }
     return;
   }
-  const T* dp = (const T*)a.d + row * a.C;
-  float v[MAXI][CH];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     int c = lane + i * 64;
     if (c < nch) {
-      Vec<T>::load(dp + c * CH, v[i]);
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
         if (MODE == MODE_ADJOINT) v[i][e] *= a.gamma[c * CH + e];
@@ -260,7 +258,12 @@ static int ln_launch(const LNArgs& a, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
   if (a.C % CH || a.C / CH > 5 * 64) { set_error("layernorm: C=%d unsupported", a.C); return -1; }
   long nrows = (long)((MODE == MODE_PRIMAL) ? a.Bp : a.NT) * a.rows_per_sample;
-  hipLaunchKernelGGL((ln_kernel<T, MODE>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, a, nrows);
+  const dim3 grid((unsigned)((nrows + 3) / 4));
+  const int need = (a.C / CH + 63) / 64;
+  if (need <= 1) hipLaunchKernelGGL((ln_kernel<T, MODE, 1>), grid, dim3(256), 0, st, a, nrows);
+  else if (need <= 2) hipLaunchKernelGGL((ln_kernel<T, MODE, 2>), grid, dim3(256), 0, st, a, nrows);
+  else if (need <= 3) hipLaunchKernelGGL((ln_kernel<T, MODE, 3>), grid, dim3(256), 0, st, a, nrows);
+  else hipLaunchKernelGGL((ln_kernel<T, MODE, 5>), grid, dim3(256), 0, st, a, nrows);
   DPB_CHECK(hipGetLastError());
   return 0;
 }
