@@ -38,19 +38,41 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
       const int ch0 = col * CH;
       float mean[CH], rstd[CH], gam[CH], bet[CH], m1[CH], m2[CH];
       int grp[CH];
-#pragma unroll
-      for (int e = 0; e < CH; ++e) {
-        grp[e] = (ch0 + e) / cpg;
-        gam[e] = a.gamma[ch0 + e];
-        bet[e] = a.beta[ch0 + e];
-        mean[e] = rstd[e] = m1[e] = m2[e] = 0.f;
+      Vec<float>::load(a.gamma + ch0, gam);
+      Vec<float>::load(a.beta + ch0, bet);
+      if constexpr (CH == 8) { Vec<float>::load(a.gamma + ch0 + 4, gam + 4); Vec<float>::load(a.beta + ch0 + 4, bet + 4); }
+      if (cpg >= CH) {
+        // a 16-byte chunk spans at most two groups: fetch their statistics once instead of once per channel
+        // (the per-channel form cost 48 dependent scalar loads per thread, as much as the thread's whole pixel walk)
+        const int g0 = ch0 / cpg, g1 = min(g0 + 1, a.G - 1);
+        float me[2] = {0.f, 0.f}, rs[2] = {0.f, 0.f}, t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
         if (MODE != MODE_PRIMAL || !STATS) {
-          mean[e] = (float)a.pstats[((long)b * a.G + grp[e]) * 2];
-          rstd[e] = (float)a.pstats[((long)b * a.G + grp[e]) * 2 + 1];
+          me[0] = (float)a.pstats[((long)b * a.G + g0) * 2]; rs[0] = (float)a.pstats[((long)b * a.G + g0) * 2 + 1];
+          me[1] = (float)a.pstats[((long)b * a.G + g1) * 2]; rs[1] = (float)a.pstats[((long)b * a.G + g1) * 2 + 1];
         }
         if (MODE != MODE_PRIMAL && !STATS) {
-          m1[e] = (float)(a.tstats[((long)j * a.G + grp[e]) * 2] * inv_n);
-          m2[e] = (float)(a.tstats[((long)j * a.G + grp[e]) * 2 + 1] * inv_n);
+          t1[0] = (float)(a.tstats[((long)j * a.G + g0) * 2] * inv_n); t2[0] = (float)(a.tstats[((long)j * a.G + g0) * 2 + 1] * inv_n);
+          t1[1] = (float)(a.tstats[((long)j * a.G + g1) * 2] * inv_n); t2[1] = (float)(a.tstats[((long)j * a.G + g1) * 2 + 1] * inv_n);
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          const int hi = (ch0 + e) >= (g0 + 1) * cpg ? 1 : 0;
+          grp[e] = g0 + hi;
+          mean[e] = me[hi]; rstd[e] = rs[hi]; m1[e] = t1[hi]; m2[e] = t2[hi];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          grp[e] = (ch0 + e) / cpg;
+          mean[e] = rstd[e] = m1[e] = m2[e] = 0.f;
+          if (MODE != MODE_PRIMAL || !STATS) {
+            mean[e] = (float)a.pstats[((long)b * a.G + grp[e]) * 2];
+            rstd[e] = (float)a.pstats[((long)b * a.G + grp[e]) * 2 + 1];
+          }
+          if (MODE != MODE_PRIMAL && !STATS) {
+            m1[e] = (float)(a.tstats[((long)j * a.G + grp[e]) * 2] * inv_n);
+            m2[e] = (float)(a.tstats[((long)j * a.G + grp[e]) * 2 + 1] * inv_n);
+          }
         }
       }
       float s1[CH], s2[CH];
@@ -136,7 +158,8 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
   if (a.C % CH || a.C % a.G || a.G > 256) { set_error("groupnorm: C=%d G=%d unsupported", a.C, a.G); return -1; }
   const int n = (MODE == MODE_PRIMAL) ? a.Bp : a.NT;
   int ppb = 64;
-  while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < 512) ppb >>= 1;
+  static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;   // tuning override
+  while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
   dim3 grid((a.HW + ppb - 1) / ppb, n);
   hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), 0, st, a, ppb);
   if (MODE == MODE_PRIMAL) {
