@@ -358,7 +358,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
       const int n = c * 8;
       const long mn = (long)m * p.N + n;
       float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int s = 0; s < p.splitk; ++s) {
+      int s = 0;
+      for (; s + 4 <= p.splitk; s += 4) {          // four slabs in flight per thread; summed in slab order (the order is part of the
+        float t[4][8];                              // bitwise kernel-equivalence contract)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) V8<float>::load(p.slab + ((long)(s + u) * Z + z) * MN + mn, t[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[u][e];
+      }
+      for (; s < p.splitk; ++s) {
         float t[8];
         V8<float>::load(p.slab + ((long)s * Z + z) * MN + mn, t);
 #pragma unroll
