@@ -35,7 +35,9 @@ template <int D> struct FA {
   static constexpr int DO = ND * 32;
   static constexpr int BI = D <= 80 ? 128 : 64;  // inner rows per LDS stage: at 128 the one-stage-ahead register prefetch has
                                                 // twice the MFMA time to land (key-major adjoint -8 %); head dim 160 would exceed the LDS
-  static constexpr int LDR = DP + 8;            // LDS stride of [row][d] tiles   (bf16 elements)
+  static constexpr int LDR = (DP > DO ? DP : DO) + 8;   // LDS stride of [row][d] tiles (bf16 elements): 36 / 52 / 84 dwords = 4 x odd, so
+                                                // ds_read_b128 fragment reads are conflict-free; >= DO columns so that the transpose
+                                                // reads of lds_tr_frag stay inside the row (columns DP.. are never consumed)
   static constexpr int LDT = BI + 4;            // LDS stride of [d][row] tiles: 68 elements = 34 dwords = 2*odd, so the 32 rows of a
                                                 // ds_read_b64 fragment read hit 32 distinct even banks (72 gave a 2-way conflict)
   static constexpr int ROW_ELEMS = BI * LDR;
@@ -116,6 +118,20 @@ __device__ inline bf16x8 lds_t_frag(const bf16* tile, int drow, int ld, int base
   uint2 lo = *reinterpret_cast<const uint2*>(tile + drow * ld + base + 4 * lhi);
   uint2 hi = *reinterpret_cast<const uint2*>(tile + drow * ld + base + 8 + 4 * lhi);
   uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+// The same A fragment ([32 d rows][16 inner rows], element j <-> inner row base + 4*lhi + (j&3) + 8*(j>>2)) read from a
+// ROW tile [inner row][d] with gfx950's LDS transpose read: a 16-lane group hands ds_read_b64_tr_b16 the [4][16] block
+// "4 inner rows x 16 d columns" (lane i: row i/4, columns 4(i%4)..+3) and lane i receives column i of it.  No per-head
+// transposed copy of the operand is needed (neither in HBM nor as a second LDS tile).
+typedef __attribute__((ext_vector_type(4))) short short4_;
+__device__ inline bf16x8 lds_tr_frag(const bf16* tile, int ld, int base, int d0, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const bf16* p = tile + (base + 4 * (g >> 1) + (i16 >> 2)) * ld + d0 + (g & 1) * 16 + (i16 & 3) * 4;
+  short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_*)p);
+  short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_*)(p + 8 * ld));
+  uint2 l2 = *reinterpret_cast<uint2*>(&lo), h2 = *reinterpret_cast<uint2*>(&hi);
+  uint4 v = make_uint4(l2.x, l2.y, h2.x, h2.y);
   return *reinterpret_cast<bf16x8*>(&v);
 }
 __device__ inline void pack_b(const float* x, bf16x8* out) {   // 16 fp32 (acc register order) -> two B fragments
@@ -477,8 +493,8 @@ template <int D, int TJ>
 __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
   using F = FA<D>;
   constexpr int NTH = 256;
-  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
-  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
+  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int ngrp = (a.kps + TJ - 1) / TJ;
   const int grp = blockIdx.y % ngrp, bh = blockIdx.y / ngrp, b = bh / a.H, h = bh % a.H;
@@ -487,7 +503,6 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
   const long LC = (long)a.L * a.C, LCo = (long)a.L * a.Co;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
-  const bf16* KTp = a.KT + ((long)b * a.H + h) * D * a.L;
   bf16x8 qf[F::NS], gof[TJ][F::NS];
   load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
   float Dq[TJ];
@@ -524,16 +539,14 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][d][r] = 0.f;
   RowRegs<D, NTH> rK, rV;
-  TRegs<D, NTH> rKT;
-  fetch_row<D, NTH>(Kp, a.C, rK, tid); fetch_row<D, NTH>(Vp, a.C, rV, tid); fetch_t<D, NTH>(KTp, a.L, rKT, tid);
+  fetch_row<D, NTH>(Kp, a.C, rK, tid); fetch_row<D, NTH>(Vp, a.C, rV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();
-    commit_row<D, NTH>(rK, sK, tid); commit_row<D, NTH>(rV, sV, tid); commit_t<D, NTH>(rKT, sKT, tid);
+    commit_row<D, NTH>(rK, sK, tid); commit_row<D, NTH>(rV, sV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {
       const int k1 = k0 + F::BI;
       fetch_row<D, NTH>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, NTH>(Vp + (long)k1 * a.C, a.C, rV, tid);
-      fetch_t<D, NTH>(KTp + k1, a.L, rKT, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < F::BI / 32; ++kb) {
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int d = 0; d < F::ND; ++d) ktf[ks][d] = lds_t_frag(sKT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+        for (int d = 0; d < F::ND; ++d) ktf[ks][d] = lds_tr_frag(sK, F::LDR, kb * 32 + ks * 16, d * 32, lane);   // K^T from the K row tile
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il;
