@@ -616,9 +616,9 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
 template <int D>
 __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
   using F = FA<D>;
-  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
   __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
-  bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS; bf16* sQT = sgO + F::ROW_ELEMS; bf16* sgOT = sQT + F::T_ELEMS;
+  bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS;     // Q^T / gO^T fragments come from these row tiles by LDS transpose reads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
@@ -628,8 +628,6 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
   const long LCo = (long)a.L * a.Co;
   const bf16* Op = a.O + b * LCo + h * D;
   const bf16* gOp = a.gO + j * LCo + h * D;
-  const bf16* QTp = a.QT + ((long)b * a.H + h) * D * a.L;
-  const bf16* gOTp = a.gOT + ((long)j * a.H + h) * D * a.L;
   const float* stp_ = a.stats + ((long)b * a.H + h) * a.L * 2;
   bf16x8 kf[F::NS], vf[F::NS];
   load_outer_frags<D>(a.K + b * LC + (long)key * a.C + h * D, kf, lhi);
@@ -641,7 +639,6 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
 #pragma unroll
     for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
   RowRegs<D> rQ, rgO;
-  TRegs<D> rQT, rgOT;
   float st0 = 0.f, st1 = 0.f, st2 = 0.f;
   auto fetch_stats = [&](int q0) {       // per-query statistics of a stage, D_q = gO_q . O_q
     if (tid < F::BI) {
@@ -659,17 +656,16 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
       st2 = dq;
     }
   };
-  fetch_row<D>(Qp, a.C, rQ, tid); fetch_row<D>(gOp, a.Co, rgO, tid); fetch_t<D>(QTp, a.L, rQT, tid); fetch_t<D>(gOTp, a.L, rgOT, tid);
+  fetch_row<D>(Qp, a.C, rQ, tid); fetch_row<D>(gOp, a.Co, rgO, tid);
   fetch_stats(0);
   for (int q0 = 0; q0 < a.L; q0 += F::BI) {
     __syncthreads();
-    commit_row<D>(rQ, sQ, tid); commit_row<D>(rgO, sgO, tid); commit_t<D>(rQT, sQT, tid); commit_t<D>(rgOT, sgOT, tid);
+    commit_row<D>(rQ, sQ, tid); commit_row<D>(rgO, sgO, tid);
     if (tid < F::BI) { sstat[0][tid] = st0; sstat[1][tid] = st1; sstat[2][tid] = st2; }
     __syncthreads();
     if (q0 + F::BI < a.L) {
       const int q1 = q0 + F::BI;
       fetch_row<D>(Qp + (long)q1 * a.C, a.C, rQ, tid); fetch_row<D>(gOp + (long)q1 * a.Co, a.Co, rgO, tid);
-      fetch_t<D>(QTp + q1, a.L, rQT, tid); fetch_t<D>(gOTp + q1, a.L, rgOT, tid);
       fetch_stats(q1);
     }
 #pragma unroll
@@ -696,8 +692,8 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int d = 0; d < F::ND; ++d) {
-          accV[d] = MFMA(lds_t_frag(sgOT, d * 32 + l31, F::LDT, qb * 32 + ks * 16, lhi), pb[ks], accV[d]);
-          accK[d] = MFMA(lds_t_frag(sQT, d * 32 + l31, F::LDT, qb * 32 + ks * 16, lhi), gsb[ks], accK[d]);
+          accV[d] = MFMA(lds_tr_frag(sgO, F::LDR, qb * 32 + ks * 16, d * 32, lane), pb[ks], accV[d]);
+          accK[d] = MFMA(lds_tr_frag(sQ, F::LDR, qb * 32 + ks * 16, d * 32, lane), gsb[ks], accK[d]);
         }
     }
   }
