@@ -175,15 +175,15 @@ struct FusedArgs {
 template <int D>
 __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
   using F = FA<D>;
-  __shared__ __attribute__((aligned(16))) bf16 sm[F::ROW_ELEMS + F::T_ELEMS];
-  bf16* sK = sm; bf16* sVT = sK + F::ROW_ELEMS;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
+  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int b = blk.y / a.H, h = blk.y % a.H;
   const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
-  const bf16* VTp = a.VT + ((long)b * a.H + h) * D * a.L;
+  const bf16* Vp = a.V + b * LC + h * D;
   bf16x8 qf[F::NS];
   load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
   const float c2 = a.scale * 1.44269504088896f;          // scores in log2 units
@@ -193,16 +193,15 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  RowRegs<D> rK;
-  TRegs<D> rVT;
-  fetch_row<D>(Kp, a.C, rK, tid); fetch_t<D>(VTp, a.L, rVT, tid);
+  RowRegs<D> rK, rV;
+  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(Vp, a.C, rV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();
-    commit_row<D>(rK, sK, tid); commit_t<D>(rVT, sVT, tid);
+    commit_row<D>(rK, sK, tid); commit_row<D>(rV, sV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {
       const int k1 = k0 + F::BI;
-      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_t<D>(VTp + k1, a.L, rVT, tid);
+      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < F::BI / 32; ++kb) {
@@ -233,7 +232,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int d = 0; d < F::ND; ++d)
-          acc[d] = MFMA(lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi), pb[ks], acc[d]);
+          acc[d] = MFMA(lds_tr_frag(sV, F::LDR, kb * 32 + ks * 16, d * 32, lane), pb[ks], acc[d]);
     }
   }
   const float il = 1.f / l;
@@ -261,8 +260,8 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
 template <int D>
 __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
   using F = FA<D>;
-  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + 2 * F::T_ELEMS];
-  bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sVT = sdK + F::ROW_ELEMS; bf16* sdVT = sVT + F::T_ELEMS;
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * F::ROW_ELEMS];
+  bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sV = sdK + F::ROW_ELEMS; bf16* sdV = sV + F::ROW_ELEMS;   // V^T / dV^T fragments: LDS transpose reads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
@@ -272,8 +271,8 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* dQp = a.dQ + j * LC + h * D;
   const bf16* dKp = a.dK + j * LC + h * D;
-  const bf16* VTp = a.VT + ((long)b * a.H + h) * D * a.L;
-  const bf16* dVTp = a.dVT + ((long)j * a.H + h) * D * a.L;
+  const bf16* Vp = a.V + b * LC + h * D;
+  const bf16* dVp = a.dV + j * LC + h * D;
   bf16x8 qf[F::NS], dqf[F::NS];
   load_outer_frags<D>(Qp + (long)q * a.C, qf, lhi);
   load_outer_frags<D>(dQp + (long)q * a.C, dqf, lhi);
@@ -286,18 +285,17 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float delta = 0.f;
-  RowRegs<D> rK, rdK;
-  TRegs<D> rVT, rdVT;
+  RowRegs<D> rK, rdK, rV, rdV;
   fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(dKp, a.C, rdK, tid);
-  fetch_t<D>(VTp, a.L, rVT, tid); fetch_t<D>(dVTp, a.L, rdVT, tid);
+  fetch_row<D>(Vp, a.C, rV, tid); fetch_row<D>(dVp, a.C, rdV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();                      // previous stage fully consumed
-    commit_row<D>(rK, sK, tid); commit_row<D>(rdK, sdK, tid); commit_t<D>(rVT, sVT, tid); commit_t<D>(rdVT, sdVT, tid);
+    commit_row<D>(rK, sK, tid); commit_row<D>(rdK, sdK, tid); commit_row<D>(rV, sV, tid); commit_row<D>(rdV, sdV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {               // prefetch the next stage under this stage's MFMAs
       const int k1 = k0 + F::BI;
       fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(dKp + (long)k1 * a.C, a.C, rdK, tid);
-      fetch_t<D>(VTp + k1, a.L, rVT, tid); fetch_t<D>(dVTp + k1, a.L, rdVT, tid);
+      fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_row<D>(dVp + (long)k1 * a.C, a.C, rdV, tid);
     }
     // Fragment reads run one step ahead of their MFMAs (explicit software pipeline; the compiler otherwise sinks every
     // ds_read to just before its use and each MFMA group waits out the LDS latency): the second-stage V^T / dV^T
@@ -320,8 +318,8 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int d = 0; d < F::ND; ++d) {
-            vf[ks][d] = lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
-            dvf[ks][d] = lds_t_frag(sdVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+            vf[ks][d] = lds_tr_frag(sV, F::LDR, kb * 32 + ks * 16, d * 32, lane);
+            dvf[ks][d] = lds_tr_frag(sdV, F::LDR, kb * 32 + ks * 16, d * 32, lane);
           }
         __builtin_amdgcn_sched_barrier(0);
       } else {
@@ -356,8 +354,8 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
 #pragma unroll
         for (int d = 0; d < F::ND; ++d) {
           if constexpr (!PIPE) {
-            vf[ks][d] = lds_t_frag(sVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
-            dvf[ks][d] = lds_t_frag(sdVT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi);
+            vf[ks][d] = lds_tr_frag(sV, F::LDR, kb * 32 + ks * 16, d * 32, lane);
+            dvf[ks][d] = lds_tr_frag(sdV, F::LDR, kb * 32 + ks * 16, d * 32, lane);
           }
           acc[d] = MFMA(vf[ks][d], xb[ks], acc[d]);
           acc[d] = MFMA(dvf[ks][d], pb[ks], acc[d]);
@@ -393,8 +391,8 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
 template <int D>
 __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   using F = FA<D>;
-  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS + F::T_ELEMS];
-  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS; bf16* sKT = sV + F::ROW_ELEMS;
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
+  bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
@@ -402,7 +400,6 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
-  const bf16* KTp = a.KT + ((long)b * a.H + h) * D * a.L;
   bf16x8 qf[F::NS], gof[F::NS], of[F::NS];
   load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
   const long LCo = (long)a.L * a.Co;
@@ -426,15 +423,14 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   RowRegs<D> rK, rV;
-  TRegs<D> rKT;
-  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(Vp, a.C, rV, tid); fetch_t<D>(KTp, a.L, rKT, tid);
+  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(Vp, a.C, rV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();
-    commit_row<D>(rK, sK, tid); commit_row<D>(rV, sV, tid); commit_t<D>(rKT, sKT, tid);
+    commit_row<D>(rK, sK, tid); commit_row<D>(rV, sV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {
       const int k1 = k0 + F::BI;
-      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_t<D>(KTp + k1, a.L, rKT, tid);
+      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < F::BI / 32; ++kb) {
@@ -455,7 +451,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int d = 0; d < F::ND; ++d)
-          acc[d] = MFMA(lds_t_frag(sKT, d * 32 + l31, F::LDT, kb * 32 + ks * 16, lhi), gsb[ks], acc[d]);
+          acc[d] = MFMA(lds_tr_frag(sK, F::LDR, kb * 32 + ks * 16, d * 32, lane), gsb[ks], acc[d]);
     }
   }
   bf16* gQp = a.gQ + j * LC + (long)q * a.C + h * D;

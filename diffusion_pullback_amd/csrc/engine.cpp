@@ -365,11 +365,9 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
   const float scale = 1.f / sqrtf((float)p.d);
   char* ws = e->ws;
   const AttnPtrs x = attn_ptrs(e, d, p, 0);
-  if (p.fused) {   // flash forward: O and the row statistics, no L x L object; keep the per-head transposes for the tangent/adjoint kernels
-    e->n_launch += 4;
-    if (int r = launch_transpose(e->dtype, x.V, ws + p.VT, B, H, (long)p.Lk * x.ldv, p.d, p.Lk, p.d, x.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
-    if (int r = launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
-    if (int r = launch_transpose(e->dtype, x.Q, ws + p.QT, B, H, (long)p.Lq * x.ldq, p.d, p.Lq, p.d, x.ldq, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+  if (p.fused) {   // flash forward: O and the row statistics, no L x L object; the kernels build transposed operand fragments with
+                   // LDS transpose reads from the row tiles, so no per-head transposed copies are kept either
+    e->n_launch += 1;
     FusedAttnArgs f;
     fill_fused(e, p, x, f, 1, scale);
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * B * H;
@@ -421,12 +419,10 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
   char* S1 = ws + e->S1;
   const AttnPtrs x = attn_ptrs(e, d, p, 0), t = attn_ptrs(e, d, p, 1);
   if (p.fused) {
-    char* T1 = ws + e->T1;
-    e->n_launch += 2;
-    if (int r = launch_transpose(e->dtype, t.V, T1, nt, H, (long)p.Lk * t.ldv, p.d, p.Lk, p.d, t.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+    e->n_launch += 1;
     FusedAttnArgs f;
     fill_fused(e, p, x, f, kps, scale);
-    f.dQ = t.Q; f.dK = t.K; f.dV = t.V; f.dVT = T1; f.dO = t.O;
+    f.dQ = t.Q; f.dK = t.K; f.dV = t.V; f.dO = t.O;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 5 * nt * H;
     return launch_attn_jvp_fused(f, nt, e->stream);
   }
@@ -481,12 +477,10 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   // first-write / accumulate flags, read up front: q, k, v may be windows of ONE buffer (fused QKV)
   const int accQ = e->ginit[d.in0], accK = p.kv_const ? 0 : e->ginit[d.in1], accV = p.kv_const ? 0 : e->ginit[d.in2];
   if (p.fused) {
-    char* T1 = ws + e->T1;
-    e->n_launch += 3;
-    if (int r = launch_transpose(e->dtype, gO, T1, nt, H, (long)p.Lq * c.ldo, p.d, p.Lq, p.d, c.ldo, p.Lqp, (long)p.d * p.Lqp, e->stream)) return r;
+    e->n_launch += 2;
     FusedAttnArgs f;
     fill_fused(e, p, x, f, kps, scale);
-    f.gO = gO; f.gOT = T1; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V;
+    f.gO = gO; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V;
     f.accQ = accQ; f.accK = accK; f.accV = accV;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;
     if (int r = launch_attn_adj_fused(f, nt, e->stream)) return r;
