@@ -11,11 +11,13 @@
 //              gK_j = scale sum_i gS_ij Q_i ,  gV_j = sum_i P_ij gO_i           [attn_adj_kv_kernel, key-major]
 //
 // Structure (all three): 4 waves per block, each wave owns 32 rows of the "outer" index (queries, or keys for the
-// kv kernel) held as MFMA B operands in registers; 64-row tiles of the "inner" index stream through LDS.  Score
+// kv kernel) held as MFMA B operands in registers; 128-row tiles of the "inner" index stream through LDS.  Score
 // products are computed transposed (inner index = MFMA row, outer = lane) so that each lane owns ONE outer row:
 // the softmax algebra is register-local and the probabilities re-enter the second MFMA as B fragments by a plain
-// fp32->bf16 pack, with no cross-lane movement.  The second-stage A operands come from the per-head transposed
-// copies ([d][L], key-contiguous) that the primal pass keeps (V^T, K^T, Q^T) or the caller provides (dV^T, gO^T).
+// fp32->bf16 pack, with no cross-lane movement.  The second-stage A operands (V^T, K^T, Q^T, dV^T, gO^T: [d][inner row]
+// fragments) are read from the SAME row tiles with gfx950's LDS transpose read (ds_read_b64_tr_b16, lds_tr_frag below):
+// no transposed copy of any operand exists in HBM or LDS.  (Only the 77-key cross-attention kernel still takes a
+// pre-transposed K^T / V^T of the constant prompt projections, made once per sample.)
 // v_mfma_f32_32x32x16_bf16 throughout; head dim padded to 48/80 for the score products and 64/96 for the outputs.
 #include "kernels.h"
 
