@@ -439,6 +439,13 @@ int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
   return t128 >= 1024;
 }
 
+// the halo-tile 3x3 convolution (gemm_halo.hip): every supported shape of the path measured faster than the implicit-GEMM rings
+int gemm_uses_halo(int dtype, const GemmArgs& a) {
+  static const int halo_env = getenv("DPB_CONV_HALO") ? atoi(getenv("DPB_CONV_HALO")) : 1;   // tuning switch (0: implicit-GEMM rings)
+  const bool want = g_force_tile == 600 || (halo_env && g_force_tile == 0 && g_dma_auto);
+  return want && dtype == DT_BF16 && conv_halo_supported(a);
+}
+
 // the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
 int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (dtype != DT_BF16 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
@@ -547,6 +554,35 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     static const int env_order = getenv("DPB_GEMM_ORDER") ? atoi(getenv("DPB_GEMM_ORDER")) : -1;   // tuning override
     const int force = g_force_order >= 0 ? g_force_order : env_order;
     a.order = force >= 0 ? force : (ub > ua ? 1 : 0);
+  }
+  {  // 3x3 stride-1 convolutions: halo-tile kernel (gemm_halo.hip), one 256x128 tile per block, K split over 64-channel chunks
+    if (gemm_uses_halo(dtype, a)) {
+      const long tiles = (long)(a.M / 256) * ((a.N + 127) / 128);
+      const int nch = a.Cin / 64;
+      long s = 1;
+      if (g_force_splitk) s = g_force_splitk;
+      else if (a.slab) {
+        // one resident block per CU: time ~ rounds x (chunks per block + ~2 chunks of prologue / epilogue); measured optimum on
+        // the path's layers (profiles/r01_gemm_microbench.txt): 64^2 -> 1, 32^2 -> 2, 16^2 -> 5 splits
+        long best = 1L << 60;
+        for (long c = 1; c <= nch; ++c) {
+          const long cost = ((tiles * c + 255) / 256) * ((nch + c - 1) / c + 2);
+          if (cost < best) { best = cost; s = c; }
+        }
+      }
+      s = std::min<long>(s, nch);
+      const long per = (long)a.M * a.N * 4;
+      if (a.slab && s * per > (long)a.slab_bytes) s = (long)a.slab_bytes / per;
+      a.splitk = (int)std::max<long>(s, 1);
+      if (int r = launch_conv_halo(a, st)) return r;
+      if (a.splitk > 1) {
+        long total = (long)a.M * a.N / 4;
+        unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+        DPB_CHECK(hipGetLastError());
+      }
+      return 0;
+    }
   }
   if (int dt = gemm_uses_dma(dtype, a)) {
     a.splitk = gemm_pick_splitk_dma(a, dt);

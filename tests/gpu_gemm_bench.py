@@ -46,7 +46,7 @@ def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((0, 0, 4)
 
 
 if __name__ == "__main__":
-    V = ((0, 0, 4), (515, 4, 4), (515, 8, 4), (515, 16, 4), (516, 4, 4), (516, 8, 4), (516, 16, 4), (517, 8, 4))
+    V = ((0, 0, 4), (515, 4, 4), (515, 8, 4), (515, 16, 4), (600, 2, 4), (600, 4, 4), (600, 5, 4), (600, 10, 4))
     run("conv3x3 8^2 1280->1280 b5", 8, 1280, 1280, 3, 5, variants=V)
     run("conv3x3 16^2 1280->1280 b5", 16, 1280, 1280, 3, 5, variants=V)
     run("conv3x3 16^2 640->1280 b5", 16, 640, 1280, 3, 5, variants=V)
@@ -54,7 +54,7 @@ if __name__ == "__main__":
     run("lin 16^2 1280->1280 b5", 16, 1280, 1280, 1, 5, variants=V)
     run("lin 16^2 1280->10240 b5", 16, 1280, 10240, 1, 5, variants=V)
     run("lin 16^2 5120->1280 b5", 16, 5120, 1280, 1, 5, variants=V)
-    V2 = ((0, 0, 4), (515, 1, 4), (516, 1, 4), (517, 1, 4), (516, 2, 4), (131, 1, 4))
+    V2 = ((0, 0, 4), (515, 1, 4), (600, 1, 4), (600, 2, 4), (600, 3, 4), (600, 5, 4))
     run("conv3x3 64^2 320->320 b5", 64, 320, 320, 3, 5, variants=V2)
     run("conv3x3 32^2 640->640 b5", 32, 640, 640, 3, 5, variants=V2)
     run("conv3x3 32^2 320->640 b5", 32, 320, 640, 3, 5, variants=V2)

@@ -175,7 +175,8 @@ def test_dma_gemm_bitwise_equals_register_gemm():
     from diffusion_pullback_amd.tape import Tape
     lib = L.load()
     g = torch.Generator().manual_seed(0)
-    cases = [(32, 320, 320, 3, 1, 1, 5), (16, 64, 200, 3, 2, 1, 3), (12, 40, 72, 3, 1, 1, 2), (20, 136, 328, 1, 1, 0, 3), (16, 64, 64, 3, 2, 0, 2)]
+    cases = [(32, 320, 320, 3, 1, 1, 5), (16, 64, 200, 3, 2, 1, 3), (12, 40, 72, 3, 1, 1, 2), (20, 136, 328, 1, 1, 0, 3), (16, 64, 64, 3, 2, 0, 2),
+             (16, 128, 200, 3, 1, 1, 2), (64, 64, 136, 3, 1, 1, 1)]       # the last two (with the first) run the halo-tile convolution: 16 / 64 pixel rows, N tails
     try:
         for (H, cin, cout, ks, stride, pad, batch) in cases:
             p = {"c.weight": torch.randn(cout, cin, ks, ks, generator=g) * 0.05, "c.bias": torch.randn(cout, generator=g)}
@@ -214,6 +215,11 @@ def test_dma_gemm_bitwise_equals_register_gemm():
                                 assert torch.equal(a, b), msg
                             else:                               # K is partitioned in 64- instead of 32-wide steps: fp32 slabs differ in association
                                 assert (a - b).norm() <= 2e-3 * a.norm(), msg
+                L.check(lib.dpb_debug_set(b"gemm_tile", 600))      # halo-tile 3x3 convolution (gemm_halo.hip) where the shape allows it:
+                for rep in range(3):                               # chunk-major K order -> fp32 association differs from the tap-major kernels
+                    got = run()
+                    for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
+                        assert (a - b).norm() <= 2e-3 * a.norm(), f"case {(H, cin, cout, ks, stride, pad)} halo kernel splitk {sk} {name} rep {rep}: rel {((a - b).norm() / a.norm()).item():.3e}"
     finally:
         L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
 

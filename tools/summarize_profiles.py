@@ -21,6 +21,8 @@ def norm(name: str) -> str:
     """'void dpb::gemm_ring64_kernel<128, 128, 2, 0, 4>(dpb::GemmArgs)' -> 'gemm_ring64_kernel<128,128,2>' (the trailing
     template arguments of the GEMM kernels are the compile-time gather mode and wave count: they share one bench label)."""
     n = re.sub(r"\(.*$", "", name.replace("void ", "").replace("dpb::", "")).replace(" ", "")
+    if n.startswith("conv_halo_kernel<"):
+        return "conv_halo_kernel"                          # forward gather and its adjoint share one bench label
     m = re.match(r"(gemm_kernel|gemm_dma_kernel|gemm_ring64_kernel)<(.*)>$", n)
     if m:
         keep = 3 if m.group(1) != "gemm_kernel" else 4          # tile (+ stages / K chunk); the rest is gather mode (and wave count)
