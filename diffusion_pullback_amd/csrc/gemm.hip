@@ -443,7 +443,8 @@ int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
 int gemm_uses_halo(int dtype, const GemmArgs& a) {
   static const int halo_env = getenv("DPB_CONV_HALO") ? atoi(getenv("DPB_CONV_HALO")) : 1;   // tuning switch (0: implicit-GEMM rings)
   const bool want = g_force_tile == 600 || (halo_env && g_force_tile == 0 && g_dma_auto);
-  return want && dtype == DT_BF16 && conv_halo_supported(a);
+  // (8x8 images, four per tile, are supported but measure no better than the split-K ring: forced only)
+  return want && dtype == DT_BF16 && conv_halo_supported(a) && (a.H * a.W >= 256 || g_force_tile == 600);
 }
 
 // the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
@@ -557,7 +558,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   }
   {  // 3x3 stride-1 convolutions: halo-tile kernel (gemm_halo.hip), one 256x128 tile per block, K split over 64-channel chunks
     if (gemm_uses_halo(dtype, a)) {
-      const long tiles = (long)(a.M / 256) * ((a.N + 127) / 128);
+      const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
       const int nch = a.Cin / 64;
       long s = 1;
       if (g_force_splitk) s = g_force_splitk;

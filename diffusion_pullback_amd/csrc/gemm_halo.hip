@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tilesN = (p.N + BN - 1) / BN, tilesM = p.M / BM;
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   {
     const int nwg = gridDim.x * gridDim.y * gridDim.z, q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
@@ -78,11 +78,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   const bf16* R = (const bf16*)p.R;
   const bf16* zero = (const bf16*)p.zeros;
 
-  // geometry: the tile = image rows y0 .. y0+RT-1 of sample smp (W divides 256, H*W is a multiple of 256)
+  // geometry: the tile = image rows y0 .. y0+RT-1 of one sample (H*W a multiple of 256), or SPT whole samples (H*W < 256,
+  // e.g. the four 8x8 images of a 256-pixel tile), each with its own zero-padded halo
   const int W = p.W, H = p.H, Cin = p.Cin, lda = p.lda, HWp = W + 2;
-  const int hw = H * W, smp = m0 / hw, y0 = (m0 - smp * hw) / W, RT = BM / W;
-  const int npix = (RT + 2) * HWp;
-
+  const int hw = H * W, SPT = hw >= BM ? 1 : BM / hw, RT = hw >= BM ? BM / W : H;
+  const int smp = m0 / hw, y0 = hw >= BM ? (m0 - smp * hw) / W : 0, nsmp = p.M / hw;
+  const int hpix = (RT + 2) * HWp, npix = SPT * hpix, tpix = RT * W;      // halo pixels per sample, per tile; output pixels per sample
   // K range in chunks of 64 input channels
   const int nch_all = Cin / 64;
   int c_begin = 0, nch = nch_all;
@@ -102,9 +103,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
     h_dst[i] = inst * 1024 < HALO_BYTES ? inst * 1024 : -1;
     h_src[i] = nullptr;
     if (pix < npix) {
-      const int hy = pix / HWp, hx = pix - hy * HWp, iy = y0 - 1 + hy, ix = hx - 1;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        h_src[i] = A + ((long)(smp * H + iy) * W + ix) * lda + ((phys ^ ((pix >> 1) & 7)) << 3);
+      const int sl = pix / hpix, rp = pix - sl * hpix, hy = rp / HWp, hx = rp - hy * HWp, iy = y0 - 1 + hy, ix = hx - 1;
+      if (smp + sl < nsmp && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        h_src[i] = A + ((long)((smp + sl) * H + iy) * W + ix) * lda + ((phys ^ ((pix >> 1) & 7)) << 3);
     }
   }
   const bf16* b_src[NIB];
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   int pixm[2];                                                            // halo pixel of the CENTRE tap for this lane's two A-fragment rows
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int m = wy * 64 + i * 32 + l31, oy = m / W, ox = m - oy * W;
-    pixm[i] = (oy + 1) * HWp + ox + 1;
+    const int m = wy * 64 + i * 32 + l31, sl = m / tpix, r = m - sl * tpix, oy = r / W, ox = r - oy * W;
+    pixm[i] = sl * hpix + (oy + 1) * HWp + ox + 1;
   }
   unsigned fb0[2];
 #pragma unroll
@@ -292,20 +293,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   }
 }
 
-// 3x3, stride 1, pad 1, forward gather or its adjoint; whole image rows per tile; 64-channel chunks; one batch entry
+// 3x3, stride 1, pad 1, forward gather or its adjoint; whole image rows (or whole small images) per tile; 64-channel chunks
 int conv_halo_supported(const GemmArgs& a) {
   if (a.gather != GATHER_CONV && a.gather != GATHER_CONVT) return 0;
   if (a.KS != 3 || a.stride != 1 || a.pad != 1 || a.Z1 * a.Z2 != 1 || a.A2) return 0;
   if (a.H != a.Ho || a.W != a.Wo || a.Cin % 64 || a.K != 9 * a.Cin) return 0;
-  if (a.W < 16 || HALO_BM % a.W || (a.H * a.W) % HALO_BM || a.M % HALO_BM) return 0;
-  if ((HALO_BM / a.W + 2) * (a.W + 2) > HALO_MAXPIX) return 0;
+  const int hw = a.H * a.W;
+  if (a.M % hw) return 0;
+  if (hw >= HALO_BM) {                              // whole image rows of one sample per tile
+    if (HALO_BM % a.W || hw % HALO_BM) return 0;
+    if ((HALO_BM / a.W + 2) * (a.W + 2) > HALO_MAXPIX) return 0;
+  } else {                                          // whole samples per tile (8x8: four)
+    if (HALO_BM % hw || a.W < 8) return 0;
+    if ((HALO_BM / hw) * (a.H + 2) * (a.W + 2) > HALO_MAXPIX) return 0;
+  }
   if (a.lda % 8 || a.ldb % 8 || !a.zeros) return 0;
   return 1;
 }
 
 int launch_conv_halo(const GemmArgs& a, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
-  dim3 grid((a.M / HALO_BM) * ((a.N + HALO_BN - 1) / HALO_BN), 1, sk);
+  dim3 grid(((a.M + HALO_BM - 1) / HALO_BM) * ((a.N + HALO_BN - 1) / HALO_BN), 1, sk);
   if (a.gather == GATHER_CONV) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT>), grid, dim3(512), 0, st, a);
   DPB_CHECK(hipGetLastError());

@@ -176,7 +176,8 @@ def test_dma_gemm_bitwise_equals_register_gemm():
     lib = L.load()
     g = torch.Generator().manual_seed(0)
     cases = [(32, 320, 320, 3, 1, 1, 5), (16, 64, 200, 3, 2, 1, 3), (12, 40, 72, 3, 1, 1, 2), (20, 136, 328, 1, 1, 0, 3), (16, 64, 64, 3, 2, 0, 2),
-             (16, 128, 200, 3, 1, 1, 2), (64, 64, 136, 3, 1, 1, 1)]       # the last two (with the first) run the halo-tile convolution: 16 / 64 pixel rows, N tails
+             (16, 128, 200, 3, 1, 1, 2), (64, 64, 136, 3, 1, 1, 1), (8, 128, 136, 3, 1, 1, 5)]   # the last three (with the first) run the halo-tile
+             # convolution: 16 / 64 pixel rows and 8x8 images (four per tile, ragged last tile), N tails
     try:
         for (H, cin, cout, ks, stride, pad, batch) in cases:
             p = {"c.weight": torch.randn(cout, cin, ks, ks, generator=g) * 0.05, "c.bias": torch.randn(cout, generator=g)}
