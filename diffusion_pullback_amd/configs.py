@@ -60,6 +60,23 @@ class SDConfig:
 
 
 SD15 = SDConfig()
+# stabilityai/stable-diffusion-2-1-base (and 2-base), the id the reference's SD scripts pass
+# (src/scripts/main_various_local_encoder_pullback_with_edit_prompt.sh:11): OpenCLIP-H context (1024 wide), 64-wide heads
+# (diffusers' ``attention_head_dim`` [5,10,20,20] is the per-block head COUNT in 0.11), Linear proj_in / proj_out.
+SD21_BASE = SDConfig(heads=(5, 10, 20, 20), cross_dim=1024, use_linear_projection=True)
+
+
+def sd_config_for(model_name: str) -> SDConfig:
+    """U-Net architecture for a Hugging Face model id; unknown ``stable-diffusion`` ids raise instead of silently
+    building the wrong network (define_argparser.py:153 accepts any id containing 'stable-diffusion')."""
+    n = model_name.lower()
+    if "stable-diffusion-v1" in n or "stable-diffusion-1" in n:
+        return SD15
+    if "stable-diffusion-2" in n and n.rstrip("/").endswith("base"):
+        return SD21_BASE
+    raise ValueError(f"unknown Stable Diffusion model id {model_name!r}: supported are the SD-v1.x family (runwayml/stable-diffusion-v1-5, "
+                     "CompVis/stable-diffusion-v1-4, ...) and stabilityai/stable-diffusion-2-base / -2-1-base (epsilon-prediction, "
+                     "64x64 latents); the 768-v models use v-prediction, which the reference's scheduler step does not implement either")
 
 
 

@@ -751,9 +751,9 @@ int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* c
   if (e->ctx_buf >= 0) {
     if (!ctx) return fail("this network needs ctx (encoder_hidden_states)");
     const Buf& bc = e->bufs[e->ctx_buf];
-    // ctx is already [batch][rows][C] channel-last: a "transpose" with C=HW roles swapped is not needed; cast via nchw kernel with HW=1
+    // ctx is already [batch][rows][Cv] channel-last (Cv = un-padded width): cast (and zero-pad to C) via the nchw kernel with HW=1
     e->n_launch++;
-    if (int r = launch_nchw_to_nhwc(e->dtype, ctx, e->P(e->ctx_buf), batch * bc.rows, bc.C, 1, bc.C, e->stream)) return r;
+    if (int r = launch_nchw_to_nhwc(e->dtype, ctx, e->P(e->ctx_buf), batch * bc.rows, bc.Cv, 1, bc.C, e->stream)) return r;
   }
   if (e->temb_buf >= 0) {
     // sinusoidal timestep embedding, computed on the host in fp32 exactly as the reference frameworks do

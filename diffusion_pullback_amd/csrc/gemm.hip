@@ -428,7 +428,7 @@ void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_forc
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 
 int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
-  // Register-staged kernel, measured on MI355X (tests/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt):
+  // Register-staged kernel, measured on MI355X (tools/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt):
   // bf16 -- the 64x64 tile (7 blocks/CU in flight) beats the 128x128 tile, which is latency-bound at <= 4 blocks/CU
   //         (large bf16 problems go to the asynchronous ring kernels instead);
   // fp32 -- the slow fp32 MFMA (64 cycles) hides the load latency: with >= 4 tiles per CU the 128x128 tile wins

@@ -1,6 +1,6 @@
 // bf16 MFMA GEMM / implicit-GEMM convolution, asynchronous global->LDS ring with 128-byte row segments (BK = 64) and an
 // in-wave software pipeline.  Second generation of gemm_dma.hip, written after ablating that kernel on MI355X
-// (tests/gpu_gemm_ablate.py, profiles/r01_gemm_ablation.txt):
+// (tools/gpu_gemm_ablate.py, profiles/r01_gemm_ablation.txt):
 //   * with BK = 32 a DMA row segment is 64 B = HALF a 128-byte cache line, so every line is requested twice (by
 //     consecutive K-steps); the DMA stream alone then costs 340 us of the 450 us a 20480x2560x2560 product takes.  With
 //     one full line per lane-octet the same bytes move ~1.7x faster  ->  BK = 64, rows 128 B apart in LDS.
@@ -18,7 +18,7 @@
 #include "kernels.h"
 
 #ifndef DPB_ABLATE
-#define DPB_ABLATE 0   // micro-benchmark builds only (tests/gpu_gemm_ablate.py): 1 no MFMA, 2 no DMA refills, 4 no LDS fragment reads,
+#define DPB_ABLATE 0   // micro-benchmark builds only (tools/gpu_gemm_ablate.py): 1 no MFMA, 2 no DMA refills, 4 no LDS fragment reads,
                        // 8 no epilogue global stores (and no bias / residual loads), 16 no epilogue at all
 #endif
 

@@ -1,5 +1,5 @@
 // Re-orthonormalisation step of the subspace iteration: thin SVD of the k x N matrix W = J^T J V_prev
-// (k <= 16, N up to 196 608), fp32 in/out with fp64 Gram and eigen-solve.
+// (k <= 56 in 16-wide column tiles, N up to 196 608), fp32 in/out with fp64 Gram and eigen-solve.
 //
 // Replaces torch.linalg.svd(v_, full_matrices=False) at reference src/utils/utils.py:799 (and :233):
 //   W = U S V^T  ->  rows of V^T (descending S) and s = sqrt(S).

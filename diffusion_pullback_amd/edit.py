@@ -62,9 +62,13 @@ class _SeededPrompts:
 class _EditBase(object):
     latent_scale = 1.0
 
-    def _chunks(self, x):
-        n = x.size(0) // self.memory_bound
-        return [x] if n == 0 else list(x.chunk(n))
+    def _chunks(self, x, per_sample: int = 1):
+        """Batches of at most ``memory_bound`` samples (edit.py:434-438), further bounded by the engine's own batch limit
+        (``per_sample`` = 2 under classifier-free guidance, which doubles the U-Net batch).  Samples are independent, so the
+        batching is not observable in the result."""
+        cap = getattr(getattr(self.unet, "engine", None), "max_batch", None)
+        bound = self.memory_bound if cap is None else max(1, min(self.memory_bound, cap // per_sample))
+        return list(x.split(bound))
 
     def _eps(self, x, t, emb=None):
         out = self.unet(x, t) if emb is None else self.unet(x, t, encoder_hidden_states=emb)
@@ -168,7 +172,7 @@ class EditStableDiffusion(_EditBase):
                 print("t_end_idx : ", t_idx)
                 return latents, t, t_idx
             outs = []
-            for lat in self._chunks(latents):
+            for lat in self._chunks(latents, 2 if do_cfg else 1):
                 if do_cfg:
                     emb = torch.cat([self.neg_prompt_emb.repeat(lat.size(0), 1, 1), self.for_prompt_emb.repeat(lat.size(0), 1, 1)], dim=0)
                     e_u, e_c = self._eps(torch.cat([lat] * 2, dim=0), t, emb).chunk(2)

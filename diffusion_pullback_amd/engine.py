@@ -95,10 +95,20 @@ class Engine:
             b = x.shape[0]
             if x[0].numel() != self.n_in:
                 raise L.DpbError(f"input has {x[0].numel()} elements per sample, network expects {self.n_in}")
-            if ctx is not None:
+            cbuf = getattr(self.tape, "ctx", -1)
+            if cbuf >= 0:
+                if ctx is None:
+                    raise L.DpbError("this network needs encoder_hidden_states (ctx)")
+                rows, cpad, _ = self.tape.buffers[cbuf]
+                width = self.tape.valid[cbuf] or cpad
+                if ctx.dim() != 3 or ctx.shape[1] != rows or ctx.shape[2] != width or ctx.shape[0] not in (1, b):
+                    raise L.DpbError(f"encoder_hidden_states has shape {tuple(ctx.shape)}, the engine was built for [{b} or 1, {rows}, {width}] "
+                                     "(token count and width are fixed at engine build time: SDConfig.ctx_len / cross_dim)")
                 ctx = _f32(ctx, self.device)
                 if ctx.shape[0] != b:
                     ctx = ctx.expand(b, -1, -1).contiguous()
+            else:
+                ctx = None
             L.check(self.lib.dpb_primal(self.h, _ptr(x), b, float(t), _ptr(ctx), buf))
             self.batch = b
 

@@ -6,12 +6,16 @@ module raises, so nothing in the product path can silently run on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import glob
+import hashlib
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdpb.so")
 CSRC = os.path.join(_HERE, "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+STAMP_PATH = LIB_PATH + ".srchash"          # content hash of the sources the .so was built from (git-ignored, travels with gpurun)
 
 DPB_F32, DPB_BF16 = 0, 1
 OP_CONV, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_GEGLU, OP_SILU, OP_CONCAT = 1, 2, 3, 4, 5, 6, 7
@@ -69,6 +73,26 @@ class DpbError(RuntimeError):
     pass
 
 
+def _source_hash() -> str:
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp"))
+                   + [os.path.join(CSRC, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "dpb.h")])
+    for f in files:
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def _built_hash() -> str:
+    try:
+        with open(STAMP_PATH) as fh:
+            return fh.read().strip() if os.path.exists(LIB_PATH) else ""
+    except OSError:
+        return ""
+
+
 def build(force: bool = False) -> str:
     """Compile libdpb.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
@@ -76,6 +100,8 @@ def build(force: bool = False) -> str:
     r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
     if r.returncode != 0:
         raise DpbError("hipcc build of libdpb.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(_source_hash())
     return LIB_PATH
 
 
@@ -84,13 +110,21 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
-        import fcntl                     # fresh checkout: compile the HIP library in-tree (never a CPU substitute);
-        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:      # one builder when several ranks start together
+    if os.path.exists(HIPCC) and os.path.isdir(CSRC) and os.access(_HERE, os.W_OK) and _source_hash() != _built_hash():
+        # the sources changed since libdpb.so was linked (or it was never built): rebuild in-tree, incrementally -- an edited
+        # .hip / dpb.h never runs against a stale binary, and never against a CPU substitute.  The stamp is a content hash, not
+        # mtimes, so a copied tree (gpurun snapshot) with a matching .so does not rebuild.  One builder when several ranks
+        # start together; the lock lives outside the package.
+        import fcntl
+        import tempfile
+        lock = os.path.join(tempfile.gettempdir(), "dpb-build-%s.lock" % hashlib.sha1(_HERE.encode()).hexdigest()[:12])
+        with open(lock, "w") as lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
-            if not os.path.exists(LIB_PATH):
-                build()
-            fcntl.flock(lk, fcntl.LOCK_UN)
+            try:
+                if _source_hash() != _built_hash():
+                    build()
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     if not os.path.exists(LIB_PATH):
         raise DpbError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the product path)")

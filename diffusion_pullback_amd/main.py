@@ -111,19 +111,29 @@ def preset(args):
 
 
 def build_unet(args) -> PullbackUNet:
+    from . import weights as W
     small = args.net_scale != "full"
+    # U-Net batch: memory_bound latents of the decode loop (x2 under classifier-free guidance), never below the 2 of x-space guidance
+    max_batch = max(2, min(args.memory_bound, args.vis_num + 1) * (2 if args.guidance_scale > 1.0 else 1))
     if args.is_stable_diffusion:
-        cfg = cf.SD15 if not small else cf.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True),
-                                                    heads=(2, 2), cross_dim=64, groups=8, sample_size=16)
+        cfg = cf.sd_config_for(args.model_name)           # SD-v1.x or SD-2(.1)-base; anything else raises
+        if small:
+            cfg = cf.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True),
+                              heads=(2, 2), cross_dim=64, groups=8, sample_size=16, use_linear_projection=cfg.use_linear_projection)
         params = torch.load(args.weights, map_location="cpu") if args.weights else cf.sd_init_params(cfg, seed=args.seed)
+        W.check_shapes(params, cf.sd_param_shapes(cfg), f"{args.model_name} U-Net")
         if small:
             args.image_size = cfg.sample_size
-        return PullbackUNet("sd", cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=5, max_rank=max(args.pca_rank, 2))
+        return PullbackUNet("sd", cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=max_batch, max_rank=max(args.pca_rank, 2))
     cfg = cf.CELEBA_HQ_256 if not small else cf.DDPMConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,), resolution=32)
-    params = torch.load(args.weights, map_location="cpu") if args.weights else cf.ddpm_init_params(cfg, seed=args.seed)
+    if args.weights:                                      # diffusers UNet2DModel keys (google/ddpm-ema-celebahq-256) or vendored names
+        params = W.ddpm_hf_to_vendored_names(torch.load(args.weights, map_location="cpu"), cfg)
+    else:
+        params = cf.ddpm_init_params(cfg, seed=args.seed)
+    W.check_shapes(params, cf.ddpm_param_shapes(cfg), f"{args.model_name} U-Net")
     if small:
         args.image_size = cfg.resolution
-    return PullbackUNet("ddpm", cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=5, max_rank=max(args.pca_rank, 2))
+    return PullbackUNet("ddpm", cfg, params, dtype=args.compute_dtype, device=args.device, max_batch=max_batch, max_rank=max(args.pca_rank, 2))
 
 
 def build_vae(args):

@@ -151,9 +151,14 @@ class PullbackUNet:
 
 def bind(unet, kind: str, cfg, dtype=torch.float32, device="cuda:0", **kw) -> PullbackUNet:
     """Attach the HIP-backed methods onto an existing U-Net module, like the reference's
-    ``types.MethodType`` injection (utils.py:103-104, :326-337).  ``unet.state_dict()`` must use the
-    parameter naming of the matching builder (tape.build_ddpm / tape.build_sd)."""
-    impl = PullbackUNet(kind, cfg, {k: v.detach().cpu() for k, v in unet.state_dict().items()}, dtype, device, **kw)
+    ``types.MethodType`` injection (utils.py:103-104, :326-337).  ``unet.state_dict()`` uses diffusers' keys: ``UNet2DConditionModel`` for "sd"
+    (consumed as is by tape.build_sd), ``UNet2DModel`` for "ddpm" (renamed by weights.ddpm_hf_to_vendored_names; the vendored
+    naming of src/models/ddpm/diffusion.py is accepted unchanged)."""
+    sd = {k: v.detach().cpu() for k, v in unet.state_dict().items()}
+    if kind == "ddpm":                    # diffusers UNet2DModel keys (the reference's live path, utils.py:101-104) -> builder names
+        from .weights import ddpm_hf_to_vendored_names
+        sd = ddpm_hf_to_vendored_names(sd, cfg)
+    impl = PullbackUNet(kind, cfg, sd, dtype, device, **kw)
     unet._dpb = impl
     unet.get_h = types.MethodType(lambda self, *a, **k: self._dpb.get_h(*a, **k), unet)
     if kind == "sd":

@@ -246,7 +246,7 @@ def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None)
     e0 = t.conv("time_embedding.linear_1", t.temb_in, (1, 1), cfg.temb_ch, ks=1, need_adj=False, kind=L.BUF_SHARED)
     e1 = t.conv("time_embedding.linear_2", t.silu(e0), (1, 1), cfg.temb_ch, ks=1, need_adj=False, kind=L.BUF_SHARED)
     st = t.silu(e1)
-    t.ctx = t.buf(cfg.ctx_len, _r8(cfg.cross_dim))
+    t.ctx = t.buf(cfg.ctx_len, _r8(cfg.cross_dim), valid=cfg.cross_dim if cfg.cross_dim % 8 else 0)
     t.x = t.buf(s * s, _r8(cfg.in_channels))
 
     def resnet(pre, x, cin, cout, r):

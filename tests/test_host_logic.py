@@ -95,3 +95,67 @@ def test_tape_structure_clip_text():
     assert sum(1 for o in t.ops if o["kind"] == 6 and o["ip"][0] == 1) == 2                           # quick-GELU
     assert t.tap_shape[t.taps["last_hidden_state"]] == (16, 8, 1) and t.buffers[t.x][:2] == (8, 16)
     assert all(o["w"][1] == 0 for o in t.ops if o["kind"] == 1)
+
+
+def test_hf_unet2dmodel_key_map_roundtrip():
+    """google/ddpm-ema-celebahq-256 is loaded through diffusers by the reference's live path (utils.py:101-104): its UNet2DModel
+    state-dict keys must map one-to-one onto the names tape.build_ddpm reads (pure rename, weights untouched)."""
+    from diffusion_pullback_amd import configs as cf
+    from diffusion_pullback_amd import weights as W
+    from diffusion_pullback_amd.tape import build_ddpm
+    cfg = cf.DDPMConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,), resolution=32)
+    p = cf.ddpm_init_params(cfg, seed=3)
+    hf = W.ddpm_vendored_to_hf_names(p, cfg)
+    assert "time_embedding.linear_1.weight" in hf and "down_blocks.0.resnets.0.time_emb_proj.bias" in hf
+    assert "mid_block.attentions.0.query.weight" in hf and hf["mid_block.attentions.0.query.weight"].dim() == 2   # Linear in diffusers
+    assert "up_blocks.0.resnets.0.conv_shortcut.weight" in hf            # up_blocks.0 = bottleneck level = vendored up.2
+    assert "up_blocks.0.upsamplers.0.conv.weight" in hf and "up_blocks.2.upsamplers.0.conv.weight" not in hf
+    assert "conv_norm_out.weight" in hf and not any(k.startswith(("down.", "up.", "mid.", "temb.")) for k in hf)
+    back = W.ddpm_hf_to_vendored_names(hf, cfg)
+    assert set(back) == set(p)
+    for k in p:
+        assert torch.equal(back[k].reshape(p[k].shape), p[k]), k
+    W.check_shapes(back, cf.ddpm_param_shapes(cfg), "small DDPM")
+    t = build_ddpm(cfg, back, torch.float32, "cpu")                       # 2-D attention projections are accepted by the tape
+    assert t.tap_shape[t.taps[("mid", 0)]] == (64, 8, 8)
+    # later diffusers releases renamed the attention projections
+    hf2 = {k.replace(".query.", ".to_q.").replace(".key.", ".to_k.").replace(".value.", ".to_v.").replace(".proj_attn.", ".to_out.0."): v
+           for k, v in hf.items()}
+    assert set(W.ddpm_hf_to_vendored_names(hf2, cfg)) == set(p)
+    assert W.ddpm_hf_to_vendored_names(p, cfg).keys() == p.keys()         # vendored names pass through
+    with pytest.raises(KeyError):
+        W.ddpm_hf_to_vendored_names({"down_blocks.0.resnets.0.bogus.weight": torch.zeros(1)}, cfg)
+    # full-size key set: every parameter of the 256x256 architecture is reachable from an HF-named dict
+    full = cf.ddpm_param_shapes(cf.CELEBA_HQ_256)
+    fake = {k: torch.empty(0) for k in full}
+    assert set(W.ddpm_hf_to_vendored_names(W.ddpm_vendored_to_hf_names(fake, cf.CELEBA_HQ_256), cf.CELEBA_HQ_256)) == set(full)
+
+
+def test_sd_model_id_selects_architecture(tmp_path):
+    from diffusion_pullback_amd import configs as cf
+    from diffusion_pullback_amd import weights as W
+    from diffusion_pullback_amd.tape import build_sd
+    assert cf.sd_config_for("runwayml/stable-diffusion-v1-5") is cf.SD15
+    assert cf.sd_config_for("CompVis/stable-diffusion-v1-4") is cf.SD15
+    c21 = cf.sd_config_for("stabilityai/stable-diffusion-2-1-base")       # the id the reference's SD scripts pass
+    assert c21 is cf.SD21_BASE and c21.cross_dim == 1024 and c21.heads == (5, 10, 20, 20) and c21.use_linear_projection
+    assert cf.sd_config_for("stabilityai/stable-diffusion-2-base") is cf.SD21_BASE
+    for bad in ("stabilityai/stable-diffusion-2-1", "stabilityai/stable-diffusion-xl-base-1.0", "foo/stable-diffusion-3"):
+        with pytest.raises(ValueError):
+            cf.sd_config_for(bad)
+    s21 = cf.sd_param_shapes(c21)
+    assert s21["mid_block.attentions.0.proj_in.weight"] == (1280, 1280)                       # Linear, not 1x1 conv
+    assert s21["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 1024)
+    assert sum(int(torch.tensor(v).prod()) for v in s21.values()) == 865_910_724              # SD-2.1-base U-Net parameter count
+    # SD-2.1-shaped weights under an SD-1.5 config (and vice versa) are rejected with a readable message
+    tiny15 = cf.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(2, 2),
+                         cross_dim=16, groups=8, sample_size=8, ctx_len=5)
+    tiny21 = cf.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(1, 2),
+                         cross_dim=24, groups=8, sample_size=8, ctx_len=5, use_linear_projection=True)
+    p21 = cf.sd_init_params(tiny21)
+    with pytest.raises(ValueError, match="does not match"):
+        W.check_shapes(p21, cf.sd_param_shapes(tiny15), "tiny SD-1.5")
+    W.check_shapes(p21, cf.sd_param_shapes(tiny21), "tiny SD-2.1")
+    t = build_sd(tiny21, p21, torch.bfloat16, "cpu", upto=("mid", 0))      # per-block head counts + Linear projections build
+    heads = [o["ip"][0] for o in t.ops if o["kind"] == 4]
+    assert heads == [1, 1, 2, 2]                                           # down0 self/cross (1 head), mid self/cross (heads[-1] = 2)

@@ -1,8 +1,8 @@
 """Not a test: prints per-tap (primal, jvp, vjp) relative errors of the HIP engine vs the oracle.
-Usage on the GPU box:  python tests/gpu_diag.py > gpurun_out/diag.txt 2>&1"""
+Usage on the GPU box:  python tools/gpu_diag.py > gpurun_out/diag.txt 2>&1"""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from test_gpu_parity import _toy_sd, _small_ddpm, check_passes
 from diffusion_pullback_amd import PullbackUNet

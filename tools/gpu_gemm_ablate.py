@@ -1,6 +1,6 @@
 """Not a test: ablation of the LDS-DMA ring GEMM (which side bounds the K loop?).  Each variant is a separate build of
 gemm_dma.hip with -DDPB_ABLATE=bits (1 = no MFMA, 2 = no DMA refills, 4 = no LDS fragment reads) linked into
-csrc/build/abl<bits>/libdpb.so;  run as  `for ab in 0 1 2 3 4 5 6 7; do python tests/gpu_gemm_ablate.py $ab; done`."""
+csrc/build/abl<bits>/libdpb.so;  run as  `for ab in 0 1 2 3 4 5 6 7; do python tools/gpu_gemm_ablate.py $ab; done`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Not a test: micro-benchmark of the GEMM/implicit-GEMM kernel on the pullback path's layer shapes through 1-op tapes.
-python tests/gpu_gemm_bench.py > gpurun_out/gemm_bench.txt"""
+python tools/gpu_gemm_bench.py > gpurun_out/gemm_bench.txt"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

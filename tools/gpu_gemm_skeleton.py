@@ -1,6 +1,6 @@
 """Not a test: true (kernel-trace) durations of short-K ring GEMMs for an ablation build (argv[1] = DPB_ABLATE bits, csrc `make ablate`)."""
 import os, sys
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffusion_pullback_amd import lib as L
 ab = int(sys.argv[1])
 if ab: L.LIB_PATH = os.path.join(L.CSRC, "build", f"abl{ab}", "libdpb.so")
