@@ -138,7 +138,40 @@ def ddpm_param_shapes(cfg: DDPMConfig) -> Dict[str, Tuple[int, ...]]:
     return s
 
 
-def ddpm_init_params(cfg: DDPMConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32) -> Params:
+@dataclass(frozen=True)
+class Spectrum:
+    """Spectrum shaping of the synthetic weights (SURVEY.md section 7 "parity is subtle (ii)").
+
+    Random-init U-Nets have a nearly flat top of the Jacobian spectrum (sigma_1..5 within 1 % of each other on SD-1.5), so
+    individual singular vectors are ill-conditioned and "top-5 |cos| >= 0.99" cannot be tested; trained networks have the
+    fast-decaying spectra the paper reports.  No weight of these architectures is indexed by position, so the only place a
+    synthetic network can hold a few dominant GLOBAL directions is a token-pooling op: the mid-block self-attention.  Shaping
+    adds ``rank`` seeded channel directions to its output projection,  W_o += amp * sum_i decay^i a_i b_i^T  (a_i, b_i
+    orthonormal), and scales its query projection by ``q_scale`` (near-uniform attention = mean pooling over the 8x8 tokens,
+    as in an untrained attention layer).  The Jacobian then has ``rank`` leading singular values ~ amp * decay^i * c whose
+    right vectors are (upstream Jacobian)^T applied to the pooled b_i directions -- they run through every down-block kernel --
+    above the flat bulk.  Architecture, shapes and FLOPs are untouched."""
+    rank: int = 12
+    decay: float = 0.8
+    amp: float = 400.0
+    q_scale: float = 0.1
+
+
+def _shape_spectrum(p: Params, w_out: str, w_q: str, sp: Spectrum, seed: int) -> None:
+    if w_out not in p:                       # prefix-restricted parameter sets that stop before the mid block
+        return
+    g = torch.Generator().manual_seed(seed + 7919)           # own stream: every other parameter keeps its unshaped bits
+    w = p[w_out]
+    c = w.shape[0]
+    r = min(sp.rank, c)
+    a = torch.linalg.qr(torch.randn(c, r, generator=g))[0]
+    b = torch.linalg.qr(torch.randn(c, r, generator=g))[0]
+    spike = (a * (sp.amp * sp.decay ** torch.arange(r, dtype=torch.float32))[None, :]) @ b.T
+    p[w_out] = (w.float() + spike.reshape(w.shape)).to(w.dtype)
+    p[w_q] = (p[w_q].float() * sp.q_scale).to(w.dtype)
+
+
+def ddpm_init_params(cfg: DDPMConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32, spectrum: "Spectrum | None" = None) -> Params:
     """Seeded synthetic weights (no checkpoints are reachable offline).
 
     Fan-in scaled normal for matrices, GroupNorm affine near identity.  Generated on
@@ -153,6 +186,8 @@ def ddpm_init_params(cfg: DDPMConfig, seed: int = 0, gain: float = 1.0, dtype=to
         else:
             fan_in = math.prod(shp[1:])
             p[name] = (gain * torch.randn(shp, generator=g) / math.sqrt(fan_in)).to(dtype)
+    if spectrum is not None:
+        _shape_spectrum(p, "mid.attn_1.proj_out.weight", "mid.attn_1.q.weight", spectrum, seed)
     return p
 
 
@@ -222,7 +257,8 @@ def sd_param_shapes(cfg: SDConfig) -> Dict[str, Tuple[int, ...]]:
     return s
 
 
-def sd_init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32, only_prefix=None) -> Params:
+def sd_init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.float32, only_prefix=None,
+                   spectrum: "Spectrum | None" = None) -> Params:
     """Seeded synthetic weights at the exact architecture shapes (CPU generator)."""
     g = torch.Generator().manual_seed(seed)
     p: Params = {}
@@ -235,6 +271,9 @@ def sd_init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.
             t = gain * torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[1:]))
         if only_prefix is None or name.startswith(only_prefix):
             p[name] = t.to(dtype)
+    if spectrum is not None:
+        tb = "mid_block.attentions.0.transformer_blocks.0.attn1."
+        _shape_spectrum(p, tb + "to_out.0.weight", tb + "to_q.weight", spectrum, seed)
     return p
 
 

@@ -161,9 +161,9 @@ static int pick_fwd(T* S, long nrows, int Lk, int ld, int causal_Lq, hipStream_t
 }
 
 int launch_softmax_fwd(int dtype, void* S, long Z, int Lq, int Lk, int ld, int causal, hipStream_t st) {
-  if (ld % (dtype == DT_F32 ? 4 : 8)) { set_error("softmax: ld=%d not chunk aligned", ld); return -1; }
+  if (ld % dt_chunk(dtype)) { set_error("softmax: ld=%d not chunk aligned", ld); return -1; }
   const int cq = causal ? Lq : 0;
-  return dtype == DT_F32 ? pick_fwd<float>((float*)S, Z * Lq, Lk, ld, cq, st) : pick_fwd<bf16>((bf16*)S, Z * Lq, Lk, ld, cq, st);
+  return DPB_DISPATCH_T(dtype, T, pick_fwd<T>((T*)S, Z * Lq, Lk, ld, cq, st));
 }
 
 template <typename T>
@@ -183,19 +183,15 @@ static int pick_jvp(const T* P, T* dS, float* D, long nrows, int Z2, int kps, in
 
 int launch_softmax_jvp(int dtype, const void* P, void* dS, float* D, long Z, int Z2, int kps, int Lq, int Lk, int ld,
                        hipStream_t st) {
-  if (ld % (dtype == DT_F32 ? 4 : 8)) { set_error("softmax: ld=%d not chunk aligned", ld); return -1; }
-  return dtype == DT_F32 ? pick_jvp<float>((const float*)P, (float*)dS, D, Z * Lq, Z2, kps, Lq, Lk, ld, st)
-                         : pick_jvp<bf16>((const bf16*)P, (bf16*)dS, D, Z * Lq, Z2, kps, Lq, Lk, ld, st);
+  if (ld % dt_chunk(dtype)) { set_error("softmax: ld=%d not chunk aligned", ld); return -1; }
+  return DPB_DISPATCH_T(dtype, T, pick_jvp<T>((const T*)P, (T*)dS, D, Z * Lq, Z2, kps, Lq, Lk, ld, st));
 }
 
 int launch_softmax_adjT(int dtype, const void* PT, void* gPT, const float* D, long Z, int Z2, int kps, int Lk, int Lq, int ld,
                         hipStream_t st) {
-  long total = Z * Lk * (ld / (dtype == DT_F32 ? 4 : 8));
+  long total = Z * Lk * (ld / dt_chunk(dtype));
   unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL((softmax_adjT_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)PT, (float*)gPT, D, Z, Z2, kps, Lk, Lq, ld);
-  else
-    hipLaunchKernelGGL((softmax_adjT_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)PT, (bf16*)gPT, D, Z, Z2, kps, Lk, Lq, ld);
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((softmax_adjT_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)PT, (T*)gPT, D, Z, Z2, kps, Lk, Lq, ld));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
@@ -203,7 +199,7 @@ int launch_softmax_adjT(int dtype, const void* PT, void* gPT, const float* D, lo
 int launch_transpose(int dtype, const void* in, void* out, int Z1, int Z2, long s1, long s2, int R, int Ccols, int ldin, int ldout,
                      long outZstride, hipStream_t st) {
   dim3 grid((ldout + 31) / 32, (Ccols + 31) / 32, Z1 * Z2);
-  if (dtype == DT_F32)
+  if (dtype == DT_F32)   // pure data movement: the two 16-bit types share the bf16 instantiation
     hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)in, (float*)out, Z2, s1, s2, R, Ccols, ldin, ldout, outZstride);
   else
     hipLaunchKernelGGL((transpose_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)in, (bf16*)out, Z2, s1, s2, R, Ccols, ldin, ldout, outZstride);

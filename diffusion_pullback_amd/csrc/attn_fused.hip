@@ -23,8 +23,6 @@
 
 namespace dpb {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int att_waves(int d) { return d > 80 ? 4 : 8; }   // waves per block: 8 x 32 = 256 outer rows share every streamed tile
                                                             // (head dim 160: 4 waves, the fragments need the 512-register budget)
@@ -136,11 +134,10 @@ __device__ inline bf16x8 lds_tr_frag(const bf16* tile, int ld, int base, int d0,
   uint4 v = make_uint4(l2.x, l2.y, h2.x, h2.y);
   return *reinterpret_cast<bf16x8*>(&v);
 }
+template <int FL>
 __device__ inline void pack_b(const float* x, bf16x8* out) {   // 16 fp32 (acc register order) -> two B fragments
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[ks][i] = (__bf16)x[ks * 8 + i];       // v_cvt_pk_bf16_f32
+  out[0] = H16<FL>::pack8(x);                                   // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
+  out[1] = H16<FL>::pack8(x + 8);
 }
 // XCD-aware block mapping.  Workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest); the blocks of
 // one (tangent, head) group stream the SAME inner tensors, so they should share an L2: with the natural order the 16
@@ -154,7 +151,7 @@ __device__ inline BlockXY xcd_group_blocks(int on) {
   return {slot % nx, (slot / nx) * 8 + xcd};
 }
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA(a, b, c) H16<FL>::mfma(a, b, c)   // FL: the enclosing kernel's 16-bit flavour (0 bf16, 1 f16)
 
 struct FusedArgs {
   const bf16 *Q, *K, *V, *O;          // primal [B][L][C]
@@ -174,7 +171,7 @@ struct FusedArgs {
 // O = softmax(scale Q K^T) V with online softmax; also emits the row statistics (m, 1/l) the tangent / adjoint
 // kernels need, so the L x L probabilities are never materialised for the fused layers.  Same tiling as below:
 // lane <-> query, so the running max / sum and the rescale of the accumulator are register-local.
-template <int D>
+template <int D, int FL>
 __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
@@ -229,7 +226,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
       bf16x8 pb[2];
-      pack_b(p, pb);
+      pack_b<FL>(p, pb);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -250,16 +247,14 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
     for (int g = 0; g < 4; ++g) {
       const int col = d * 32 + 8 * g + 4 * lhi;
       if (col < D) {
-        bf16x8 tmp;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tmp[i] = (__bf16)(acc[d][g * 4 + i] * il);
-        *reinterpret_cast<uint2*>(Op + col) = *reinterpret_cast<uint2*>(&tmp);
+        *reinterpret_cast<uint2*>(Op + col) = make_uint2(H16<FL>::pack2(acc[d][g * 4] * il, acc[d][g * 4 + 1] * il),
+                                                         H16<FL>::pack2(acc[d][g * 4 + 2] * il, acc[d][g * 4 + 3] * il));
       }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ tangent
-template <int D>
+template <int D, int FL>
 __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * F::ROW_ELEMS];
@@ -349,8 +344,8 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
         delta += x[r];
       }
       bf16x8 pb[2], xb[2];
-      pack_b(p, pb);
-      pack_b(x, xb);
+      pack_b<FL>(p, pb);
+      pack_b<FL>(x, xb);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -380,9 +375,9 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
         unsigned w[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          float o0 = __uint_as_float(ow[i] << 16), o1 = __uint_as_float(ow[i] & 0xffff0000u);
+          float o0 = H16<FL>::lo(ow[i]), o1 = H16<FL>::hi(ow[i]);
           float v0 = acc[d][g * 4 + 2 * i] - delta * o0, v1 = acc[d][g * 4 + 2 * i + 1] - delta * o1;
-          w[i] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+          w[i] = H16<FL>::pack2(v0, v1);
         }
         *reinterpret_cast<uint2*>(dOp + col) = make_uint2(w[0], w[1]);
       }
@@ -390,7 +385,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ adjoint, query-major (gQ)
-template <int D>
+template <int D, int FL>
 __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
@@ -413,7 +408,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
     const unsigned short* g16 = reinterpret_cast<const unsigned short*>(&gof[stp]);
     const unsigned short* o16 = reinterpret_cast<const unsigned short*>(&of[stp]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Dq += bf2f(g16[e]) * bf2f(o16[e]);
+    for (int e = 0; e < 8; ++e) Dq += H16<FL>::up(g16[e]) * H16<FL>::up(o16[e]);
   }
   Dq += __shfl_xor(Dq, 32, 64);
   const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
@@ -448,7 +443,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) gs[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il * (gp[r] - Dq);
       bf16x8 gsb[2];
-      pack_b(gs, gsb);
+      pack_b<FL>(gs, gsb);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -468,11 +463,11 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
         for (int i = 0; i < 4; ++i) v[i] = a.scale * acc[d][g * 4 + i];
         if (a.accQ) {
           uint2 ov = *reinterpret_cast<const uint2*>(gQp + col);
-          v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
-          v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+          v[0] += H16<FL>::lo(ov.x); v[1] += H16<FL>::hi(ov.x);
+          v[2] += H16<FL>::lo(ov.y); v[3] += H16<FL>::hi(ov.y);
         }
         *reinterpret_cast<uint2*>(gQp + col) =
-            make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            make_uint2(H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
       }
     }
 }
@@ -487,7 +482,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
 // tangent in every stage; with one 4-wave block per CU its 49 KB-per-32-keys stream is latency-bound -- measured 760-870 us
 // against 430 us for attn_jvp_kernel -- so only the query-major adjoint, whose streamed tiles are all shared, uses it.)
 // 4 waves (one per SIMD, up to 512 registers each: TJ*ND accumulators + TJ*NS cotangent fragments stay in registers).
-template <int D, int TJ>
+template <int D, int TJ, int FL>
 __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
   using F = FA<D>;
   constexpr int NTH = 256;
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
           const unsigned short* g16 = reinterpret_cast<const unsigned short*>(&gof[t][stp]);
           const unsigned short* o16 = reinterpret_cast<const unsigned short*>(&of[stp]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) Dq[t] += bf2f(g16[e]) * bf2f(o16[e]);
+          for (int e = 0; e < 8; ++e) Dq[t] += H16<FL>::up(g16[e]) * H16<FL>::up(o16[e]);
         }
         Dq[t] += __shfl_xor(Dq[t], 32, 64);
       } else {
@@ -576,7 +571,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) gs[r] = p[r] * (gp[r] - Dq[t]);
           bf16x8 gsb[2];
-          pack_b(gs, gsb);
+          pack_b<FL>(gs, gsb);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -600,18 +595,18 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
           for (int i = 0; i < 4; ++i) v[i] = a.scale * acc[t][d][g * 4 + i];
           if (a.accQ) {
             uint2 ov = *reinterpret_cast<const uint2*>(gQp + col);
-            v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
-            v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+            v[0] += H16<FL>::lo(ov.x); v[1] += H16<FL>::hi(ov.x);
+            v[2] += H16<FL>::lo(ov.y); v[3] += H16<FL>::hi(ov.y);
           }
           *reinterpret_cast<uint2*>(gQp + col) =
-              make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+              make_uint2(H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
         }
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
-template <int D>
+template <int D, int FL>
 __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
@@ -646,8 +641,8 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
       float dq = 0.f;
       for (int c = 0; c < D; c += 8) {
         float g8[8], o8[8];
-        Vec<bf16>::load(gOp + (long)qq * a.Co + c, g8);
-        Vec<bf16>::load(Op + (long)qq * a.Co + c, o8);
+        H16<FL>::load8(gOp + (long)qq * a.Co + c, g8);
+        H16<FL>::load8(Op + (long)qq * a.Co + c, o8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq += g8[e] * o8[e];
       }
@@ -684,8 +679,8 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
         gs[r] = p[r] * (gp[r] - sstat[2][qi]);
       }
       bf16x8 pb[2], gsb[2];
-      pack_b(p, pb);
-      pack_b(gs, gsb);
+      pack_b<FL>(p, pb);
+      pack_b<FL>(gs, gsb);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -708,18 +703,18 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
         for (int i = 0; i < 4; ++i) { vk[i] = a.scale * accK[d][g * 4 + i]; vv[i] = accV[d][g * 4 + i]; }
         if (a.accK) {
           uint2 ov = *reinterpret_cast<const uint2*>(gKp + col);
-          vk[0] += __uint_as_float(ov.x << 16); vk[1] += __uint_as_float(ov.x & 0xffff0000u);
-          vk[2] += __uint_as_float(ov.y << 16); vk[3] += __uint_as_float(ov.y & 0xffff0000u);
+          vk[0] += H16<FL>::lo(ov.x); vk[1] += H16<FL>::hi(ov.x);
+          vk[2] += H16<FL>::lo(ov.y); vk[3] += H16<FL>::hi(ov.y);
         }
         if (a.accV) {
           uint2 ov = *reinterpret_cast<const uint2*>(gVp + col);
-          vv[0] += __uint_as_float(ov.x << 16); vv[1] += __uint_as_float(ov.x & 0xffff0000u);
-          vv[2] += __uint_as_float(ov.y << 16); vv[3] += __uint_as_float(ov.y & 0xffff0000u);
+          vv[0] += H16<FL>::lo(ov.x); vv[1] += H16<FL>::hi(ov.x);
+          vv[2] += H16<FL>::lo(ov.y); vv[3] += H16<FL>::hi(ov.y);
         }
         *reinterpret_cast<uint2*>(gKp + col) =
-            make_uint2((unsigned)f2bf(vk[0]) | ((unsigned)f2bf(vk[1]) << 16), (unsigned)f2bf(vk[2]) | ((unsigned)f2bf(vk[3]) << 16));
+            make_uint2(H16<FL>::pack2(vk[0], vk[1]), H16<FL>::pack2(vk[2], vk[3]));
         *reinterpret_cast<uint2*>(gVp + col) =
-            make_uint2((unsigned)f2bf(vv[0]) | ((unsigned)f2bf(vv[1]) << 16), (unsigned)f2bf(vv[2]) | ((unsigned)f2bf(vv[3]) << 16));
+            make_uint2(H16<FL>::pack2(vv[0], vv[1]), H16<FL>::pack2(vv[2], vv[3]));
       }
     }
 }
@@ -741,7 +736,7 @@ struct CrossArgs {
 };
 constexpr int XKEYS = 96, XLDT = XKEYS + 4;
 
-template <int D>
+template <int D, int FL>
 __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
   using F = FA<D>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * XKEYS * F::LDR + F::DO * XLDT];
@@ -830,7 +825,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) w[r] = t[kb][r] - delta * s[kb][r];
     bf16x8 wb[2];
-    pack_b(w, wb);
+    pack_b<FL>(w, wb);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -849,17 +844,30 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
         for (int i = 0; i < 4; ++i) v[i] = a.c_out * acc[d][g * 4 + i];
         if (a.accumulate) {
           uint2 ov = *reinterpret_cast<const uint2*>(Yp + col);
-          v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
-          v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+          v[0] += H16<FL>::lo(ov.x); v[1] += H16<FL>::hi(ov.x);
+          v[2] += H16<FL>::lo(ov.y); v[3] += H16<FL>::hi(ov.y);
         }
         *reinterpret_cast<uint2*>(Yp + col) =
-            make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            make_uint2(H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
       }
     }
 }
 
+// head dims with a kernel instantiation: 40 / 80 / 160 (SD-1.x), 64 (SD-2.x: every level has 64-wide heads)
+static bool head_dim_ok(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }
+// expands `stmt` with D = the head dim and FL = the 16-bit flavour as compile-time constants
+#define DPB_ATT_DISPATCH(d, fl, ...)                                                        \
+  do {                                                                                       \
+    if ((fl) == 0) { constexpr int FL = 0; DPB_ATT_D(d, __VA_ARGS__) } else { constexpr int FL = 1; DPB_ATT_D(d, __VA_ARGS__) } \
+  } while (0)
+#define DPB_ATT_D(d, ...)                                          \
+  if ((d) == 40) { constexpr int D = 40; __VA_ARGS__; }            \
+  else if ((d) == 64) { constexpr int D = 64; __VA_ARGS__; }       \
+  else if ((d) == 80) { constexpr int D = 80; __VA_ARGS__; }       \
+  else { constexpr int D = 160; __VA_ARGS__; }
+
 int cross_attention_supported(int dtype, int d, int Lq, int Lk, int kv_const) {
-  return dtype == DT_BF16 && kv_const && (d == 40 || d == 80 || d == 160) && Lk <= XKEYS && Lq % 32 == 0 && (Lq >= 128 ? Lq % 128 == 0 : true);
+  return dtype != DT_F32 && kv_const && head_dim_ok(d) && Lk <= XKEYS && Lq % 32 == 0 && (Lq >= 128 ? Lq % 128 == 0 : true);
 }
 
 int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st) {
@@ -871,16 +879,15 @@ int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st) {
   a.c_in = f.adjoint ? 1.f : f.scale; a.c_out = f.adjoint ? f.scale : 1.f;
   const int waves = f.L >= 128 ? 4 : f.L / 32;
   dim3 grid(f.L / (waves * 32), nt * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_cross_kernel<40>), grid, dim3(waves * 64), 0, st, a);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_cross_kernel<80>), grid, dim3(waves * 64), 0, st, a);
-  else if (f.d == 160) hipLaunchKernelGGL((attn_cross_kernel<160>), grid, dim3(waves * 64), 0, st, a);
-  else { set_error("cross attention: head dim %d unsupported", f.d); return -1; }
+  if (!head_dim_ok(f.d)) { set_error("cross attention: head dim %d unsupported", f.d); return -1; }
+  DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_cross_kernel<D, FL>), grid, dim3(waves * 64), 0, st, a));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
 // row statistics of the primal probabilities from the materialised scaled scores S (before softmax):
 // one wave per row; stats[row] = (max, 1 / sum exp(S - max))
+template <int FL>
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* stats, long nrows, int Lk, int ld) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* st
   float m = -INFINITY;
   for (int c = lane * 8; c < Lk; c += 512) {
     float v[8];
-    Vec<bf16>::load(sp + c, v);
+    H16<FL>::load8(sp + c, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (c + e < Lk) m = fmaxf(m, v[e]);
   }
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* st
   float s = 0.f;
   for (int c = lane * 8; c < Lk; c += 512) {
     float v[8];
-    Vec<bf16>::load(sp + c, v);
+    H16<FL>::load8(sp + c, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (c + e < Lk) s += __expf(v[e] - m);
   }
@@ -906,11 +913,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* st
 }
 
 int fused_attention_supported(int dtype, int d, int L, int kv_const) {
-  return dtype == DT_BF16 && !kv_const && (d == 40 || d == 80 || d == 160) && L >= 256 && L % (att_waves(d) * 32) == 0;
+  return dtype != DT_F32 && !kv_const && head_dim_ok(d) && L >= 256 && L % (att_waves(d) * 32) == 0;
 }
 
-int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, (const bf16*)S, stats, nrows, Lk, ld);
+int launch_row_stats(int fl, const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st) {
+  if (fl) hipLaunchKernelGGL((row_stats_kernel<1>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, (const bf16*)S, stats, nrows, Lk, ld);
+  else hipLaunchKernelGGL((row_stats_kernel<0>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, (const bf16*)S, stats, nrows, Lk, ld);
   DPB_CHECK(hipGetLastError());
   return 0;
 }
@@ -932,10 +940,8 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st) {
   FusedArgs a = to_args(f);
   dim3 grid(f.L / (att_waves(f.d) * 32), batch * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_fwd_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a, (bf16*)O, stats);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a, (bf16*)O, stats);
-  else if (f.d == 160) hipLaunchKernelGGL((attn_fwd_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a, (bf16*)O, stats);
-  else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_fwd_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a, (bf16*)O, stats));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
@@ -943,10 +949,8 @@ int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* sta
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
   dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
-  if (f.d == 40) hipLaunchKernelGGL((attn_jvp_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  else if (f.d == 80) hipLaunchKernelGGL((attn_jvp_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  else if (f.d == 160) hipLaunchKernelGGL((attn_jvp_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_jvp_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
@@ -955,21 +959,17 @@ int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
   dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
   static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernel (tuning switch)
+  if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   if (f.d == 40 && (multi & 1) && f.L % 128 == 0 && nt % f.kps == 0) {
     constexpr int TJ = 5;
     const int ngrp = (f.kps + TJ - 1) / TJ;
-    hipLaunchKernelGGL((attn_adj_q_multi_kernel<40, TJ>), dim3(f.L / 128, (nt / f.kps) * f.H * ngrp), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  } else if (f.d == 40) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<40>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  } else if (f.d == 80) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<80>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  } else if (f.d == 160) {
-    hipLaunchKernelGGL((attn_adj_q_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-    hipLaunchKernelGGL((attn_adj_kv_kernel<160>), grid, dim3(att_waves(f.d) * 64), 0, st, a);
-  } else { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+    const dim3 gq(f.L / 128, (nt / f.kps) * f.H * ngrp);
+    if (f.fl) hipLaunchKernelGGL((attn_adj_q_multi_kernel<40, TJ, 1>), gq, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_adj_q_multi_kernel<40, TJ, 0>), gq, dim3(256), 0, st, a);
+  } else {
+    DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_q_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
+  }
+  DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_kv_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   DPB_CHECK(hipGetLastError());
   return 0;
 }

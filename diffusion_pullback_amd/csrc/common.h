@@ -5,9 +5,12 @@
 
 namespace dpb {
 
-enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 
-struct bf16 {
+struct bf16 {   // bfloat16 storage; the specialised 16-bit kernels also use it as RAW 16-bit storage (flavour FL, H16<FL> below)
+  unsigned short v;
+};
+struct f16 {    // IEEE half storage
   unsigned short v;
 };
 
@@ -30,6 +33,15 @@ __host__ __device__ inline unsigned short f2bf(float f) {   // round to nearest 
 #endif
 }
 
+__device__ inline float h2f(unsigned short v) {
+  _Float16 h = *reinterpret_cast<_Float16*>(&v);
+  return (float)h;
+}
+__device__ inline unsigned short f2h(float f) {   // round to nearest even (v_cvt_f16_f32); overflow -> inf
+  _Float16 h = (_Float16)f;
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+
 template <typename T> struct TT;
 template <> struct TT<float> {
   static constexpr int CH = 4;                 // elements per 16-byte chunk
@@ -40,6 +52,12 @@ template <> struct TT<bf16> {
   static constexpr int CH = 8;
   __device__ static inline float ld(const bf16* p) { return bf2f(p->v); }
   __device__ static inline void st(bf16* p, float v) { p->v = f2bf(v); }
+};
+
+template <> struct TT<f16> {
+  static constexpr int CH = 8;
+  __device__ static inline float ld(const f16* p) { return h2f(p->v); }
+  __device__ static inline void st(f16* p, float v) { p->v = f2h(v); }
 };
 
 // 16-byte vector load/store <-> float[CH]
@@ -73,6 +91,84 @@ template <> struct Vec<bf16> {
     *reinterpret_cast<v8*>(p) = r;
   }
 };
+
+template <> struct Vec<f16> {
+  static constexpr int N = 8;
+  typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+  __device__ static inline void load(const f16* p, float* o) {
+    v8 r = *reinterpret_cast<const v8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)r[i];            // v_cvt_f32_f16
+  }
+  __device__ static inline void store(f16* p, const float* o) {
+    v8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (_Float16)o[i];          // 4 x v_cvt_pk_f16_f32
+    *reinterpret_cast<v8*>(p) = r;
+  }
+};
+
+// 16-bit flavour of the specialised MFMA kernels (LDS-ring GEMMs, halo convolution, fused attention).  Those kernels only move
+// 16-bit words except at three places -- the MFMA opcode, fp32 -> 16-bit packing, 16-bit -> fp32 unpacking -- so they keep ONE
+// raw storage type (struct bf16) and take the flavour as a template parameter: FL = 0 bfloat16, FL = 1 IEEE half.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int FL> struct H16;
+template <> struct H16<0> {
+  typedef bf16 T;
+  __device__ static inline float up(unsigned short v) { return bf2f(v); }
+  __device__ static inline unsigned short dn(float f) { return f2bf(f); }
+  __device__ static inline float lo(unsigned w) { return __uint_as_float(w << 16); }            // halves of a packed pair
+  __device__ static inline float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+  __device__ static inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+  __device__ static inline f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  __device__ static inline void load8(const bf16* p, float* o) { Vec<bf16>::load(p, o); }
+  __device__ static inline void store8(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
+  __device__ static inline bf16x8 pack8(const float* x) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)x[i];           // v_cvt_pk_bf16_f32
+    return r;
+  }
+};
+template <> struct H16<1> {
+  typedef f16 T;
+  __device__ static inline float up(unsigned short v) { return h2f(v); }
+  __device__ static inline unsigned short dn(float f) { return f2h(f); }
+  __device__ static inline float lo(unsigned w) { return h2f((unsigned short)(w & 0xffffu)); }
+  __device__ static inline float hi(unsigned w) { return h2f((unsigned short)(w >> 16)); }
+  __device__ static inline unsigned pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    h2 r = {(_Float16)a, (_Float16)b};                        // v_cvt_pk_f16_f32
+    return *reinterpret_cast<unsigned*>(&r);
+  }
+  __device__ static inline f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8*>(&a), *reinterpret_cast<f16x8*>(&b), c, 0, 0, 0);
+  }
+  __device__ static inline void load8(const bf16* p, float* o) { Vec<f16>::load(reinterpret_cast<const f16*>(p), o); }
+  __device__ static inline void store8(bf16* p, const float* o) { Vec<f16>::store(reinterpret_cast<f16*>(p), o); }
+  __device__ static inline bf16x8 pack8(const float* x) {
+    f16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (_Float16)x[i];         // v_cvt_pk_f16_f32
+    return *reinterpret_cast<bf16x8*>(&r);
+  }
+};
+template <int FL> __device__ inline float ld16(const bf16* p) { return H16<FL>::up(p->v); }
+template <int FL> __device__ inline void st16(bf16* p, float v) { p->v = H16<FL>::dn(v); }
+
+// run `call` with T = float | bf16 | f16 according to the engine dtype
+#define DPB_DISPATCH_T(dtype, T, call) \
+  ((dtype) == dpb::DT_F32 ? [&] { using T = float; return call; }() : (dtype) == dpb::DT_BF16 ? [&] { using T = dpb::bf16; return call; }() : [&] { using T = dpb::f16; return call; }())
+// statement form (kernel launches): `...` is compiled with T = float | bf16 | f16
+#define DPB_DISPATCH_STMT(dtype, T, ...)                                              \
+  do {                                                                                \
+    if ((dtype) == dpb::DT_F32) { using T = float; __VA_ARGS__; }                     \
+    else if ((dtype) == dpb::DT_BF16) { using T = dpb::bf16; __VA_ARGS__; }           \
+    else { using T = dpb::f16; __VA_ARGS__; }                                         \
+  } while (0)
+inline int dt_chunk(int dtype) { return dtype == DT_F32 ? 4 : 8; }   // elements per 16-byte chunk
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -73,7 +73,7 @@ static int geglu_t(int mode, const GegluArgs& a, hipStream_t st) {
   return 0;
 }
 int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st) {
-  return dtype == DT_F32 ? geglu_t<float>(mode, a, st) : geglu_t<bf16>(mode, a, st);
+  return DPB_DISPATCH_T(dtype, T, geglu_t<T>(mode, a, st));
 }
 
 template <typename T, int OP>   // 0: silu  1: y = x  2: y += x  3: quick_gelu
@@ -111,10 +111,10 @@ static int unary_t(int op, const void* x, void* y, long n, hipStream_t st) {
   return 0;
 }
 int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st) {
-  return dtype == DT_F32 ? unary_t<float>(0, x, y, n, st) : unary_t<bf16>(0, x, y, n, st);
+  return DPB_DISPATCH_T(dtype, T, unary_t<T>(0, x, y, n, st));
 }
 int launch_quick_gelu(int dtype, const void* x, void* y, long n, hipStream_t st) {
-  return dtype == DT_F32 ? unary_t<float>(3, x, y, n, st) : unary_t<bf16>(3, x, y, n, st);
+  return DPB_DISPATCH_T(dtype, T, unary_t<T>(3, x, y, n, st));
 }
 
 // token + position embedding lookup of the text encoder, written in the engine's fp32 [b][c][t] boundary layout
@@ -128,15 +128,14 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* ids, const
 }
 int launch_embed_tokens(int dtype, const int* ids, const void* tok, const void* pos, float* out, int batch, int L, int C, int vocab, hipStream_t st) {
   if (batch <= 0 || L <= 0 || C <= 0 || vocab <= 0) { set_error("embed_tokens: empty problem"); return -1; }
-  if (dtype == DT_F32) hipLaunchKernelGGL((embed_tokens_kernel<float>), dim3(L, batch), dim3(256), 0, st, ids, (const float*)tok, (const float*)pos, out, L, C, vocab);
-  else hipLaunchKernelGGL((embed_tokens_kernel<bf16>), dim3(L, batch), dim3(256), 0, st, ids, (const bf16*)tok, (const bf16*)pos, out, L, C, vocab);
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((embed_tokens_kernel<T>), dim3(L, batch), dim3(256), 0, st, ids, (const T*)tok, (const T*)pos, out, L, C, vocab));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
 int launch_axpy(int dtype, const void* x, void* y, long n, int accumulate, hipStream_t st) {
   int op = accumulate ? 2 : 1;
-  return dtype == DT_F32 ? unary_t<float>(op, x, y, n, st) : unary_t<bf16>(op, x, y, n, st);
+  return DPB_DISPATCH_T(dtype, T, unary_t<T>(op, x, y, n, st));
 }
 
 template <typename T>
@@ -162,13 +161,10 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T* src, int lds_, 
 }
 int launch_copy_cols(int dtype, const void* src, int lds_, int cs0, void* dst, int ldd, int cd0, long rows, int ncols, int accumulate,
                      hipStream_t st) {
-  int CH = dtype == DT_F32 ? 4 : 8;
+  int CH = dt_chunk(dtype);
   if (ncols % CH || cs0 % CH || cd0 % CH || lds_ % CH || ldd % CH) { set_error("copy_cols: misaligned window"); return -1; }
   unsigned g = grid_for(rows * (ncols / CH));
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL((copy_cols_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, lds_, cs0, (float*)dst, ldd, cd0, rows, ncols, accumulate);
-  else
-    hipLaunchKernelGGL((copy_cols_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)src, lds_, cs0, (bf16*)dst, ldd, cd0, rows, ncols, accumulate);
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((copy_cols_kernel<T>), dim3(g), dim3(256), 0, st, (const T*)src, lds_, cs0, (T*)dst, ldd, cd0, rows, ncols, accumulate));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
@@ -208,15 +204,13 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* 
 }
 int launch_nchw_to_nhwc(int dtype, const float* src, void* dst, int n, int C, int HW, int Cpad, hipStream_t st) {
   dim3 grid((HW + 31) / 32, (Cpad + 31) / 32, n);
-  if (dtype == DT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), 0, st, src, (float*)dst, C, HW, Cpad);
-  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16>), grid, dim3(256), 0, st, src, (bf16*)dst, C, HW, Cpad);
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), grid, dim3(256), 0, st, src, (T*)dst, C, HW, Cpad));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 int launch_nhwc_to_nchw(int dtype, const void* src, float* dst, int n, int C, int HW, int Cpad, hipStream_t st) {
   dim3 grid((HW + 31) / 32, (C + 31) / 32, n);
-  if (dtype == DT_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), grid, dim3(256), 0, st, (const float*)src, dst, C, HW, Cpad);
-  else hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, dst, C, HW, Cpad);
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), grid, dim3(256), 0, st, (const T*)src, dst, C, HW, Cpad));
   DPB_CHECK(hipGetLastError());
   return 0;
 }
@@ -256,10 +250,9 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const T* in, T* out, int n
   }
 }
 int launch_pool2x2_sum(int dtype, const void* in, void* out, int n, int H, int W, int C, int accumulate, hipStream_t st) {
-  int CH = dtype == DT_F32 ? 4 : 8;
+  int CH = dt_chunk(dtype);
   unsigned g = grid_for((long)n * H * W * (C / CH));
-  if (dtype == DT_F32) hipLaunchKernelGGL((pool2x2_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)in, (float*)out, n, H, W, C, accumulate);
-  else hipLaunchKernelGGL((pool2x2_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)in, (bf16*)out, n, H, W, C, accumulate);
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((pool2x2_kernel<T>), dim3(g), dim3(256), 0, st, (const T*)in, (T*)out, n, H, W, C, accumulate));
   DPB_CHECK(hipGetLastError());
   return 0;
 }

@@ -382,7 +382,7 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
   e->n_launch += 3;
   if (p.fused) {
     e->n_launch++;
-    if (int r = launch_row_stats(ws + p.P, (float*)(ws + p.stats), (long)B * H * p.Lq, p.Lk, p.Lkp, e->stream)) return r;
+    if (int r = launch_row_stats(e->dtype == DT_F16, ws + p.P, (float*)(ws + p.stats), (long)B * H * p.Lq, p.Lk, p.Lkp, e->stream)) return r;
   }
   if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, p.causal, e->stream)) return r;
   // V^T, K^T per head ([d][Lkp], zero padded)
@@ -407,7 +407,7 @@ static void fill_fused(dpb_engine* e, const AttnPlan& p, const AttnPtrs& x, Fuse
   char* ws = e->ws;
   f.Q = x.Q; f.K = x.K; f.V = x.V; f.O = x.O; f.VT = ws + p.VT; f.KT = ws + p.KT; f.QT = ws + p.QT;
   f.stats = (const float*)(ws + p.stats);
-  f.L = p.Lq; f.C = x.ldq; f.Co = x.ldo; f.H = p.heads; f.d = p.d; f.kps = kps; f.scale = scale;
+  f.L = p.Lq; f.C = x.ldq; f.Co = x.ldo; f.H = p.heads; f.d = p.d; f.kps = kps; f.scale = scale; f.fl = e->dtype == DT_F16;
 }
 
 int attn_tangent(dpb_engine* e, const Op& op, int nt) {
@@ -430,7 +430,7 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
     CrossAttnArgs f;
     f.Q = x.Q; f.K = x.K; f.V = x.V; f.BT = ws + p.VT; f.X = t.Q; f.Y = t.O;
     f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = t.ldq; f.Cy = t.ldo;
-    f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 0; f.scale = scale;
+    f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 0; f.scale = scale; f.fl = e->dtype == DT_F16;
     e->n_launch++;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
     return launch_attn_cross(f, nt, e->stream);
@@ -491,7 +491,7 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
     CrossAttnArgs f;
     f.Q = x.Q; f.K = x.K; f.V = x.V; f.BT = ws + p.KT; f.X = gO; f.Y = (void*)c.Q;
     f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = c.ldo; f.Cy = c.ldq;
-    f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 1; f.accumulate = accQ; f.scale = scale;
+    f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 1; f.accumulate = accQ; f.scale = scale; f.fl = e->dtype == DT_F16;
     e->n_launch++;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
     if (int r = launch_attn_cross(f, nt, e->stream)) return r;
@@ -585,7 +585,7 @@ int dpb_abi_version(void) { return DPB_ABI_VERSION; }
 
 int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   if (!net || !out) return fail("null argument");
-  if (net->dtype != DPB_F32 && net->dtype != DPB_BF16) return fail("bad dtype %d", net->dtype);
+  if (net->dtype != DPB_F32 && net->dtype != DPB_BF16 && net->dtype != DPB_F16) return fail("bad dtype %d", net->dtype);
   if (net->max_batch < 1 || net->max_tangents < 1) return fail("max_batch/max_tangents must be >= 1");
   dpb_engine* e = new dpb_engine();
   e->dtype = net->dtype;
@@ -871,7 +871,7 @@ int dpb_ddim_step(const float* x, const float* eps, float* out, float* x0, int64
 int dpb_embed_tokens(const int32_t* ids, const void* tok_table, const void* pos_table, int dtype, float* out, int batch, int tokens,
                      int channels, int vocab, void* stream) {
   if (!ids || !tok_table || !pos_table || !out) return fail("null argument");
-  if (dtype != DPB_F32 && dtype != DPB_BF16) return fail("bad dtype %d", dtype);
+  if (dtype != DPB_F32 && dtype != DPB_BF16 && dtype != DPB_F16) return fail("bad dtype %d", dtype);
   return launch_embed_tokens(dtype, ids, tok_table, pos_table, out, batch, tokens, channels, vocab, (hipStream_t)stream);
 }
 

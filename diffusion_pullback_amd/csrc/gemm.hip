@@ -26,8 +26,6 @@
 
 namespace dpb {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <typename T> struct V8;   // 8 consecutive elements <-> float[8]
 template <> struct V8<float> {
@@ -38,6 +36,12 @@ template <> struct V8<bf16> {
   __device__ static inline void load(const bf16* p, float* o) { Vec<bf16>::load(p, o); }
   __device__ static inline void store(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
 };
+template <> struct V8<f16> {
+  __device__ static inline void load(const f16* p, float* o) { Vec<f16>::load(p, o); }
+  __device__ static inline void store(f16* p, const float* o) { Vec<f16>::store(p, o); }
+};
+template <typename T> struct FlavourOf { static constexpr int FL = 0; };
+template <> struct FlavourOf<f16> { static constexpr int FL = 1; };
 
 template <typename T, int BM, int BN, int KCH, int GATHER>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = H16<FlavourOf<T>::FL>::mfma(a[i], b[j], acc[i][j]);
       }
     }
     if (kt + 1 < kt1) sstore(buf ^ 1);
@@ -444,12 +448,12 @@ int gemm_uses_halo(int dtype, const GemmArgs& a) {
   static const int halo_env = getenv("DPB_CONV_HALO") ? atoi(getenv("DPB_CONV_HALO")) : 1;   // tuning switch (0: implicit-GEMM rings)
   const bool want = g_force_tile == 600 || (halo_env && g_force_tile == 0 && g_dma_auto);
   // (8x8 images, four per tile, are supported but measure no better than the split-K ring: forced only)
-  return want && dtype == DT_BF16 && conv_halo_supported(a) && (a.H * a.W >= 256 || g_force_tile == 600);
+  return want && dtype != DT_F32 && conv_halo_supported(a) && (a.H * a.W >= 256 || g_force_tile == 600);
 }
 
 // the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
 int gemm_uses_dma(int dtype, const GemmArgs& a) {
-  if (dtype != DT_BF16 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
+  if (dtype == DT_F32 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
   if (g_force_tile == 129) return 128;
   if (g_force_tile == 131) return 130;
   if (g_force_tile == 133) return 132;
@@ -615,7 +619,9 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
 }
 
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
-  return dtype == DT_F32 ? launch_t<float>(dtype, a, st) : launch_t<bf16>(dtype, a, st);
+  GemmArgs b = a;
+  b.fl = dtype == DT_F16;           // 16-bit flavour of the specialised kernels (H16<fl>)
+  return DPB_DISPATCH_T(dtype, T, launch_t<T>(dtype, b, st));
 }
 
 }  // namespace dpb

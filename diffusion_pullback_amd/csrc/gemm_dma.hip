@@ -18,8 +18,6 @@
 
 namespace dpb {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -29,7 +27,7 @@ __device__ inline bf16x8 lds_read_b128(unsigned addr) {
   return v;
 }
 
-template <int BM, int BN, int S, int GATHER>
+template <int BM, int BN, int S, int GATHER, int FL = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16
 __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   constexpr int BK = 32, CH = 8;
   constexpr int NIA = BM / 64, NIB = BN / 64;                          // DMA wave-instructions per stage per wave (A, B)
@@ -220,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = H16<FL>::mfma(a[i][kk], b[j][kk], acc[i][j]);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -269,29 +267,29 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (p.rowbias) {
-          Vec<bf16>::load((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
+          H16<FL>::load8((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (R) {
-          Vec<bf16>::load(R + (long)m * p.ldr + n, b8);
+          H16<FL>::load8(R + (long)m * p.ldr + n, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (p.accumulate) {
-          Vec<bf16>::load(cp, b8);
+          H16<FL>::load8(cp, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
-        Vec<bf16>::store(cp, v);
+        H16<FL>::store8(cp, v);
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) {
           float x = p.alpha * v[e];
           if (p.bias) x += p.bias[n + e];
-          if (p.rowbias) x += TT<bf16>::ld((const bf16*)p.rowbias + (long)smp * p.N + n + e);
-          if (R) x += TT<bf16>::ld(R + (long)m * p.ldr + n + e);
-          if (p.accumulate) x += TT<bf16>::ld(cp + e);
-          TT<bf16>::st(cp + e, x);
+          if (p.rowbias) x += ld16<FL>((const bf16*)p.rowbias + (long)smp * p.N + n + e);
+          if (R) x += ld16<FL>(R + (long)m * p.ldr + n + e);
+          if (p.accumulate) x += ld16<FL>(cp + e);
+          st16<FL>(cp + e, x);
         }
       }
     }
@@ -299,14 +297,19 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   }
 }
 
+template <int BM, int BN, int S, int FL>
+static void launch_dma_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.gather) {
+    case GATHER_NONE: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL>), grid, dim3(256), 0, st, a); break;
+    case GATHER_CONV: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONV, FL>), grid, dim3(256), 0, st, a); break;
+    case GATHER_CONVT: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONVT, FL>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_UPCONV, FL>), grid, dim3(256), 0, st, a); break;
+  }
+}
 template <int BM, int BN, int S>
 static void launch_dma_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
-  switch (a.gather) {
-    case GATHER_NONE: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE>), grid, dim3(256), 0, st, a); break;
-    case GATHER_CONV: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONV>), grid, dim3(256), 0, st, a); break;
-    case GATHER_CONVT: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONVT>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_UPCONV>), grid, dim3(256), 0, st, a); break;
-  }
+  if (a.fl) launch_dma_f<BM, BN, S, 1>(a, grid, st);
+  else launch_dma_f<BM, BN, S, 0>(a, grid, st);
 }
 
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st) {

@@ -18,8 +18,6 @@
 
 namespace dpb {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -49,7 +47,7 @@ constexpr int HALO_MAXPIX = 400;
 constexpr int HALO_BYTES = ((HALO_MAXPIX * 8 + 63) / 64) * 1024;        // whole wave instructions: 51,200 B
 constexpr int HALO_BSTAGE = HALO_BN * 128, HALO_S = 3;
 
-template <int GATHER>
+template <int GATHER, int FL = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16
 __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   constexpr int BM = HALO_BM, BN = HALO_BN, WAVES = 8, NH = HALO_NH, S = HALO_S, KK = 4;
   constexpr int NIB = BN / (8 * WAVES);                                  // 2 weight DMA instructions per wave and stage
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = H16<FL>::mfma(fa[cur][i], fb[cur][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -263,29 +261,29 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (p.rowbias) {
-          Vec<bf16>::load((const bf16*)p.rowbias + (long)smpb * p.N + n, b8);
+          H16<FL>::load8((const bf16*)p.rowbias + (long)smpb * p.N + n, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (R) {
-          Vec<bf16>::load(R + (long)m * p.ldr + n, b8);
+          H16<FL>::load8(R + (long)m * p.ldr + n, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (p.accumulate) {
-          Vec<bf16>::load(cp, b8);
+          H16<FL>::load8(cp, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
-        Vec<bf16>::store(cp, v);
+        H16<FL>::store8(cp, v);
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) {
           float x = p.alpha * v[e];
           if (p.bias) x += p.bias[n + e];
-          if (p.rowbias) x += TT<bf16>::ld((const bf16*)p.rowbias + (long)smpb * p.N + n + e);
-          if (R) x += TT<bf16>::ld(R + (long)m * p.ldr + n + e);
-          if (p.accumulate) x += TT<bf16>::ld(cp + e);
-          TT<bf16>::st(cp + e, x);
+          if (p.rowbias) x += ld16<FL>((const bf16*)p.rowbias + (long)smpb * p.N + n + e);
+          if (R) x += ld16<FL>(R + (long)m * p.ldr + n + e);
+          if (p.accumulate) x += ld16<FL>(cp + e);
+          st16<FL>(cp + e, x);
         }
       }
     }
@@ -314,8 +312,13 @@ int conv_halo_supported(const GemmArgs& a) {
 int launch_conv_halo(const GemmArgs& a, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   dim3 grid(((a.M + HALO_BM - 1) / HALO_BM) * ((a.N + HALO_BN - 1) / HALO_BN), 1, sk);
-  if (a.gather == GATHER_CONV) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT>), grid, dim3(512), 0, st, a);
+  if (a.gather == GATHER_CONV) {
+    if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 0>), grid, dim3(512), 0, st, a);
+  } else {
+    if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 0>), grid, dim3(512), 0, st, a);
+  }
   DPB_CHECK(hipGetLastError());
   return 0;
 }

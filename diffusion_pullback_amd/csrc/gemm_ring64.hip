@@ -24,8 +24,6 @@
 
 namespace dpb {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -56,7 +54,7 @@ __device__ inline void wait_dma(int stages_in_flight) {   // s_waitcnt vmcnt(sta
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int S, int GATHER, int WAVES = 4>
+template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16
 __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   constexpr int BK = 64, CH = 8, KK = BK / 16;
   constexpr int NIA = BM / (8 * WAVES), NIB = BN / (8 * WAVES), U = NIA + NIB;   // DMA wave-instructions (8 rows each) per stage per wave
@@ -249,7 +247,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
             if constexpr (DPB_ABLATE & 1) {
               if constexpr (!(DPB_ABLATE & 4)) asm volatile("" ::"v"(fa[cur][i]), "v"(fb[cur][j]));
             } else {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = H16<FL>::mfma(fa[cur][i], fb[cur][j], acc[i][j]);
             }
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -311,29 +309,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (p.rowbias) {
-          Vec<bf16>::load((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
+          H16<FL>::load8((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (R) {
-          Vec<bf16>::load(R + (long)m * p.ldr + n, b8);
+          H16<FL>::load8(R + (long)m * p.ldr + n, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
         if (p.accumulate) {
-          Vec<bf16>::load(cp, b8);
+          H16<FL>::load8(cp, b8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += b8[e];
         }
-        Vec<bf16>::store(cp, v);
+        H16<FL>::store8(cp, v);
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) {
           float x = p.alpha * v[e];
           if (p.bias) x += p.bias[n + e];
-          if (p.rowbias) x += TT<bf16>::ld((const bf16*)p.rowbias + (long)smp * p.N + n + e);
-          if (R) x += TT<bf16>::ld(R + (long)m * p.ldr + n + e);
-          if (p.accumulate) x += TT<bf16>::ld(cp + e);
-          TT<bf16>::st(cp + e, x);
+          if (p.rowbias) x += ld16<FL>((const bf16*)p.rowbias + (long)smp * p.N + n + e);
+          if (R) x += ld16<FL>(R + (long)m * p.ldr + n + e);
+          if (p.accumulate) x += ld16<FL>(cp + e);
+          st16<FL>(cp + e, x);
         }
       }
     }
@@ -341,14 +339,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   }
 }
 
+template <int BM, int BN, int S, int WAVES, int FL>
+static void launch_ring64_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.gather) {
+    case GATHER_NONE: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
+    case GATHER_CONV: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONV, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
+    case GATHER_CONVT: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONVT, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_UPCONV, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
+  }
+}
 template <int BM, int BN, int S, int WAVES = 4>
 static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
-  switch (a.gather) {
-    case GATHER_NONE: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
-    case GATHER_CONV: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONV, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
-    case GATHER_CONVT: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONVT, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
-    default: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_UPCONV, WAVES>), grid, dim3(WAVES * 64), 0, st, a); break;
-  }
+  if (a.fl) launch_ring64_f<BM, BN, S, WAVES, 1>(a, grid, st);
+  else launch_ring64_f<BM, BN, S, WAVES, 0>(a, grid, st);
 }
 
 // tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),

@@ -34,6 +34,7 @@ struct GemmArgs {
   float* slab = nullptr; size_t slab_bytes = 0;
   const void* zeros = nullptr;        // >= 16 zero bytes in device memory (DMA kernel reads it for padding / out-of-range rows)
   int splitk = 1, vec_ok = 0;
+  int fl = 0;                         // 16-bit flavour of the specialised kernels: 0 bf16, 1 f16 (filled in by launch_gemm)
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
@@ -95,6 +96,7 @@ struct FusedAttnArgs {
   const void *dQ = nullptr, *dK = nullptr, *dV = nullptr, *dVT = nullptr; void* dO = nullptr;
   const void *gO = nullptr, *gOT = nullptr; void *gQ = nullptr, *gK = nullptr, *gV = nullptr;
   int accQ = 0, accK = 0, accV = 0;
+  int fl = 0;                                        // 16-bit flavour: 0 bf16, 1 f16
   int L = 0, C = 0, Co = 0, H = 0, d = 0, kps = 1;   // C: row stride of q/k/v (and their tangents / cotangents), Co: of o
   float scale = 1.f;
 };
@@ -104,12 +106,12 @@ struct CrossAttnArgs {
   const void *Q = nullptr, *K = nullptr, *V = nullptr;   // primal q [B][L][C]; k, v [B][Lk][Ck] (column windows allowed)
   const void* BT = nullptr;                              // per-head transpose [B][H][d][Lkp] of V (tangent) or K (adjoint)
   const void* X = nullptr; void* Y = nullptr;            // dQ -> dO (tangent) or gO -> gQ (adjoint)
-  int L = 0, Lk = 0, Lkp = 0, C = 0, Ck = 0, Cx = 0, Cy = 0, H = 0, d = 0, kps = 1, adjoint = 0, accumulate = 0;
+  int L = 0, Lk = 0, Lkp = 0, C = 0, Ck = 0, Cx = 0, Cy = 0, H = 0, d = 0, kps = 1, adjoint = 0, accumulate = 0, fl = 0;
   float scale = 1.f;
 };
 int cross_attention_supported(int dtype, int d, int Lq, int Lk, int kv_const);
 int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st);
-int launch_row_stats(const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st);
+int launch_row_stats(int fl, const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st);
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st);   // primal O + row statistics
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st);
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st);

@@ -173,14 +173,9 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
 }
 
 int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st) {
-  if (dtype == DT_F32) {
-    if (mode == MODE_PRIMAL) return gn_launch<float, MODE_PRIMAL>(a, st);
-    if (mode == MODE_TANGENT) return gn_launch<float, MODE_TANGENT>(a, st);
-    return gn_launch<float, MODE_ADJOINT>(a, st);
-  }
-  if (mode == MODE_PRIMAL) return gn_launch<bf16, MODE_PRIMAL>(a, st);
-  if (mode == MODE_TANGENT) return gn_launch<bf16, MODE_TANGENT>(a, st);
-  return gn_launch<bf16, MODE_ADJOINT>(a, st);
+  if (mode == MODE_PRIMAL) return DPB_DISPATCH_T(dtype, T, (gn_launch<T, MODE_PRIMAL>(a, st)));
+  if (mode == MODE_TANGENT) return DPB_DISPATCH_T(dtype, T, (gn_launch<T, MODE_TANGENT>(a, st)));
+  return DPB_DISPATCH_T(dtype, T, (gn_launch<T, MODE_ADJOINT>(a, st)));
 }
 
 // ---------------------------------------------------------------- LayerNorm: one wave per token row
@@ -292,14 +287,9 @@ static int ln_launch(const LNArgs& a, hipStream_t st) {
 }
 
 int launch_layernorm(int dtype, int mode, const LNArgs& a, hipStream_t st) {
-  if (dtype == DT_F32) {
-    if (mode == MODE_PRIMAL) return ln_launch<float, MODE_PRIMAL>(a, st);
-    if (mode == MODE_TANGENT) return ln_launch<float, MODE_TANGENT>(a, st);
-    return ln_launch<float, MODE_ADJOINT>(a, st);
-  }
-  if (mode == MODE_PRIMAL) return ln_launch<bf16, MODE_PRIMAL>(a, st);
-  if (mode == MODE_TANGENT) return ln_launch<bf16, MODE_TANGENT>(a, st);
-  return ln_launch<bf16, MODE_ADJOINT>(a, st);
+  if (mode == MODE_PRIMAL) return DPB_DISPATCH_T(dtype, T, (ln_launch<T, MODE_PRIMAL>(a, st)));
+  if (mode == MODE_TANGENT) return DPB_DISPATCH_T(dtype, T, (ln_launch<T, MODE_TANGENT>(a, st)));
+  return DPB_DISPATCH_T(dtype, T, (ln_launch<T, MODE_ADJOINT>(a, st)));
 }
 
 }  // namespace dpb

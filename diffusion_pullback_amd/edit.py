@@ -34,6 +34,8 @@ from .scheduler import get_custom_diffusion_scheduler, get_stable_diffusion_sche
 def save_image(x: torch.Tensor, path: str, nrow: Optional[int] = None) -> None:
     """Minimal stand-in for torchvision.utils.save_image (edit.py:480): images in [0,1], one row."""
     x = x.detach().float().clamp(0, 1).cpu()
+    if x.dim() == 2:                                   # a matrix (the unconditional driver saves the raw vT): one grey image
+        x = x[None, None]
     if x.dim() == 3:
         x = x[None]
     if x.shape[1] not in (1, 3):                       # latents: keep as tensor next to the requested name
@@ -46,6 +48,19 @@ def save_image(x: torch.Tensor, path: str, nrow: Optional[int] = None) -> None:
         Image.fromarray(arr.squeeze(-1) if arr.shape[-1] == 1 else arr).save(path)
     except Exception:
         torch.save(x, os.path.splitext(path)[0] + ".pt")
+
+
+def save_spectrum_plot(s: torch.Tensor, path: str, dpi=None) -> None:
+    """Scatter plot of the singular values next to the cached basis (edit.py:249-251 / :733-735); skipped without matplotlib."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+    except Exception:
+        return
+    plt.scatter(range(s.size(0)), s.detach().float().cpu().tolist(), s=1)
+    plt.savefig(path, **({"dpi": dpi} if dpi else {}))
+    plt.close()
 
 
 class _SeededPrompts:
@@ -219,6 +234,13 @@ class EditStableDiffusion(_EditBase):
                 pca_rank=pca_rank, chunk_size=5, min_iter=10, max_iter=50, convergence_threshold=1e-4)   # edit.py:236-239
             vT = vT.to(device=self.device, dtype=self.dtype)
             torch.save(u, u_path); torch.save(s, s_path); torch.save(vT, vT_path)
+            save_spectrum_plot(s, os.path.join(save_dir, f"eigenvalue_spectrum-{name}.png"))        # edit.py:249-251
+            # vT shown through the 3 principal channel directions of its pixels, min-max normalised (edit.py:253-263)
+            pix = vT.view(-1, *zT.shape[1:]).permute(0, 2, 3, 1).reshape(-1, zT.shape[1]).float()
+            _, _, basis = torch.pca_lowrank(pix, q=min(3, pix.shape[1]), center=True, niter=2)
+            vis = torch.einsum("bcwh,cp->bpwh", vT.view(-1, *zT.shape[1:]).float(), basis)
+            vis = vis - vis.min()
+            save_image(vis / vis.max(), os.path.join(self.obs_folder, f"vT-{name}.png"))
         self.last_basis = (u, vT)
         u = u / u.norm(dim=0, keepdim=True)                                                     # edit.py:267-268
         vT = vT / vT.norm(dim=1, keepdim=True)
@@ -344,6 +366,8 @@ class EditUncondDiffusion(_EditBase):
             u, s, vT = self.unet.local_encoder_pullback_xt(x=xt.to(device=self.device, dtype=self.dtype), t=t, op=op, block_idx=block_idx,
                                                            pca_rank=pca_rank, min_iter=10, max_iter=50, convergence_threshold=1e-4)
             torch.save(u, u_path); torch.save(vT, vT_path)
+            save_spectrum_plot(s, os.path.join(save_dir, f"eigenvalue_spectrum-{name}.png"), dpi=80)   # edit.py:733-735
+            save_image(vT, os.path.join(self.obs_folder, f"vT-{name}.png"))                              # edit.py:737-741 (saves the raw vT)
         self.last_basis = (u, vT)
         u = u / u.norm(dim=0, keepdim=True)
         vT = vT / vT.norm(dim=1, keepdim=True)

@@ -45,7 +45,7 @@ class Engine:
                 o.w[j] = d["w"][j] or None
         self._ops = ops
         net = L.NetDesc()
-        net.dtype = L.DPB_F32 if tape.dtype == torch.float32 else L.DPB_BF16
+        net.dtype = L.dtype_code(tape.dtype)
         net.max_batch, net.max_tangents = max_batch, max_tangents
         net.n_buffers, net.n_ops = nb, no
         net.buffers, net.ops = self._bufs, self._ops

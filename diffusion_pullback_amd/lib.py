@@ -17,7 +17,16 @@ CSRC = os.path.join(_HERE, "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 STAMP_PATH = LIB_PATH + ".srchash"          # content hash of the sources the .so was built from (git-ignored, travels with gpurun)
 
-DPB_F32, DPB_BF16 = 0, 1
+DPB_F32, DPB_BF16, DPB_F16 = 0, 1, 2
+
+
+def dtype_code(dtype) -> int:
+    """torch dtype of the engine (storage + MFMA input type) -> DPB_* code of include/dpb.h"""
+    import torch
+    try:
+        return {torch.float32: DPB_F32, torch.bfloat16: DPB_BF16, torch.float16: DPB_F16}[dtype]
+    except KeyError:
+        raise DpbError(f"engine dtype must be float32, bfloat16 or float16, got {dtype}") from None
 OP_CONV, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_GEGLU, OP_SILU, OP_CONCAT = 1, 2, 3, 4, 5, 6, 7
 GATHER_NONE, GATHER_CONV, GATHER_UPCONV = 0, 1, 3
 BUF_ACT, BUF_SHARED = 0, 1

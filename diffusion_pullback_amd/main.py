@@ -92,9 +92,9 @@ def preset(args):
     os.makedirs(args.obs_folder, exist_ok=True)
     os.makedirs(args.result_folder, exist_ok=True)
     args.device = torch.device(args.device)
-    args.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(args.dtype)
+    args.compute_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}.get(args.dtype)   # define_argparser.py:196 (+ bf16)
     if args.compute_dtype is None:
-        raise ValueError("dtype choice: [fp32, bf16] (the reference's fp16 cannot run its own SVD, utils.py:799)")
+        raise ValueError("dtype choice: [fp32, fp16, bf16]")
     args.dtype = torch.float32                      # boundary dtype of latents
     if args.use_x_space_guidance:
         args.x_space_guidance_scale = X_SPACE_GUIDANCE_SCALE_DICT["stable-diffusion" if args.is_stable_diffusion else "uncond"][args.h_t]

@@ -105,12 +105,14 @@ class PullbackUNet:
         time_s = time.time()
         eng.primal(x, _t_float(t), ctx, key)
         U = s = None
+        self.last_history = []                                 # per-iteration ||V_prev - V||_2 (what the reference prints, utils.py:804)
         for i in range(max_iter):
             V_prev = V
             U = torch.cat([eng.jvp(key, vi) for vi in V.chunk(chunks)], dim=0)
             W = torch.cat([eng.vjp(key, ui) for ui in U.chunk(chunks)], dim=0)
             V, s, conv = eng.orth(W, V_prev)
             dist, viol = conv.tolist()                                            # the only host sync per iteration
+            self.last_history.append(dist)
             if self.verbose:
                 print(f"power method : {i}-th step convergence : ", dist)
             if viol <= thr and i > min_iter:

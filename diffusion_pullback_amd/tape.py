@@ -28,7 +28,7 @@ def _r8(c: int) -> int:
 
 class Tape:
     def __init__(self, params: Dict[str, torch.Tensor], dtype: torch.dtype, device):
-        assert dtype in (torch.float32, torch.bfloat16)
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         self.p = params
         self.dtype = dtype
         self.device = torch.device(device)

@@ -48,7 +48,7 @@ class ClipTextEncoder:
                 x = torch.empty(b, h, n, 1, dtype=torch.float32, device=self.device)      # [b][c][t]: the engine's NCHW boundary
                 st = torch.cuda.current_stream(self.device).cuda_stream
                 L.check(self.lib.dpb_embed_tokens(chunk.data_ptr(), self._tok.data_ptr(), self._pos.data_ptr(),
-                                                  L.DPB_F32 if self.dtype == torch.float32 else L.DPB_BF16, x.data_ptr(), b, n, h,
+                                                  L.dtype_code(self.dtype), x.data_ptr(), b, n, h,
                                                   self.cfg.vocab_size, C.c_void_p(st)))
             y = self.eng.forward(x, 0.0, None, "last_hidden_state")                       # [b, h, n, 1]
             outs.append(y[:, :, :, 0].transpose(1, 2).contiguous())

@@ -27,7 +27,7 @@ extern "C" {
 
 #define DPB_ABI_VERSION 1
 
-enum { DPB_F32 = 0, DPB_BF16 = 1 };   /* storage + MFMA input type; accumulation is always fp32 */
+enum { DPB_F32 = 0, DPB_BF16 = 1, DPB_F16 = 2 };   /* storage + MFMA input type; accumulation is always fp32 */
 
 /* ---- network description: a tape of NHWC ops over numbered activation buffers ------------- */
 enum {
@@ -65,7 +65,7 @@ typedef struct dpb_op_desc {
 } dpb_op_desc;
 
 typedef struct dpb_net_desc {
-  int32_t dtype;             /* DPB_F32 | DPB_BF16 */
+  int32_t dtype;             /* DPB_F32 | DPB_BF16 | DPB_F16 */
   int32_t max_batch;         /* max primal samples per call */
   int32_t max_tangents;      /* max total tangents/cotangents per call (k * samples) */
   int32_t n_buffers, n_ops;

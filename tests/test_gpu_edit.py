@@ -143,3 +143,128 @@ def test_sd_driver_with_on_device_vae_and_prompt_encoder(tmp_path):
     from PIL import Image
     im = Image.open(os.path.join(ed.result_folder, sorted(pngs)[0]))
     assert im.size[1] == 2 * a.image_size                               # small VAE: 2x upsampling of the 16x16 latents
+
+
+# ---------------------------------------------------------------- the drivers vs fixtures recorded from the reference's own methods
+class _Rec:
+    """records every U-Net call (t, input) of a driver run; everything else is delegated to the wrapped PullbackUNet"""
+
+    def __init__(self, net):
+        self._net, self.calls = net, []
+
+    def __call__(self, x, t, *a, **k):
+        self.calls.append((float(t), x.detach().float().cpu().clone()))
+        return self._net(x, t, *a, **k)
+
+    def __getattr__(self, n):
+        return getattr(self._net, n)
+
+
+def _compare_trace(calls, f, flipped, n_pre, blk, tol):
+    """the product's U-Net inputs against the reference's; ``flipped``: the product's basis vector has the opposite sign (singular
+    vectors are defined up to sign), so its '+v' edit is the reference's '-v' edit and the two edit blocks swap"""
+    order = list(range(n_pre)) + (list(range(n_pre + blk, n_pre + 2 * blk)) + list(range(n_pre, n_pre + blk)) if flipped
+                                   else list(range(n_pre, n_pre + 2 * blk)))
+    assert len(calls) == len(f["trace_t"]) == n_pre + 2 * blk, (len(calls), len(f["trace_t"]))
+    worst = 0.0
+    for i, j in enumerate(order):
+        t, x = calls[i]
+        assert t == f["trace_t"][j], (i, j, t, f["trace_t"][j])
+        assert x.shape == f["trace_x"][j].shape, (i, x.shape, f["trace_x"][j].shape)
+        worst = max(worst, rel(x, f["trace_x"][j]))
+    assert worst < tol, worst
+    return worst
+
+
+def test_uncond_driver_matches_reference_driver_fixture(tmp_path, monkeypatch):
+    """Rows a10-a13: EditUncondDiffusion.run_edit_local_encoder_pullback_zt on the HIP engine against the run recorded from the
+    reference's own class on the vendored PullBackDDPM (tests/golden/make_golden_edit.py): all 64 U-Net inputs (18 inversion steps,
+    8 forward steps to edit_t, 2 x 8 x-space-guidance steps, 2 x 11 decode steps), the basis (V0 drawn under the recorded seed), the
+    .pt cache names and the images handed to save_image."""
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    from diffusion_pullback_amd import edit as E
+    from oracle import unet_ddpm
+    f = load_golden("edit_uncond_small.pt")
+    a = f["args"]
+    cfg = unet_ddpm.DDPMConfig(**f["cfg"])
+    params = cf.ddpm_init_params(cfg, seed=f["seed"], spectrum=cf.Spectrum(**f["spectrum"]))
+    net = _Rec(PullbackUNet("ddpm", cfg, params, dtype=torch.float32, device=DEV, max_batch=5, max_rank=2, verbose=False))
+    args = _uncond_args(tmp_path, for_steps=a["for_steps"], inv_steps=a["inv_steps"], edit_t=a["edit_t"], x_space_guidance_edit_step=a["x_space_guidance_edit_step"],
+                        x_space_guidance_scale=a["x_space_guidance_scale"], x_space_guidance_num_step=a["x_space_guidance_num_step"], image_size=32, seed=a["seed"])
+    saved = []
+    monkeypatch.setattr(E, "save_image", lambda x, path, nrow=None: saved.append((os.path.basename(path), x.detach().float().cpu().clone())))
+    ed = E.EditUncondDiffusion(args, unet=net, dataset={a["idx"]: f["x0"]})
+    ed.performance_boosting_t_idx = 1000                   # as in the fixture: the eta = 1 tail draws device noise
+    assert int(ed.edit_t_idx) == f["edit_t_idx"]
+    torch.manual_seed(a["rng_seed"])
+    ed.run_edit_local_encoder_pullback_zt(idx=a["idx"], vis_num=a["vis_num"], vis_num_pc=a["vis_num_pc"], pca_rank=a["pca_rank"], op="mid", block_idx=0)
+    u, vT = ed.last_basis
+    cos = abs_cos_(vT, f["vT"])
+    assert (cos > 0.999).all() and (abs_cos_(u.T, f["u"].T) > 0.999).all(), cos
+    flipped = bool((vT[0].cpu() * f["vT"][0]).sum() < 0)
+    n_pre = (a["inv_steps"] - 2) + f["edit_t_idx"]
+    blk = a["x_space_guidance_num_step"] + (a["for_steps"] - 1 - f["edit_t_idx"])
+    worst = _compare_trace(net.calls, f, flipped, n_pre, blk, 2e-3)
+    ref_saved = dict(f["saved"])
+    names = [n for n, _ in saved]
+    assert names[:2] == [n for n, _ in f["saved"]][:2]                                # original_x0-*, xT-* of the inversion
+    got = dict(saved)
+    for tag, rtag in (("pos", "neg" if flipped else "pos"), ("neg", "pos" if flipped else "neg")):
+        n = f"x0_gen-Edit_xt-CelebA_HQ_0-edit_0.6T-mid-block_0-pc_000_{tag}.png"
+        assert rel(got[n], ref_saved[n.replace(tag, rtag)]) < 2e-3
+    d = os.path.join(args.input_root, os.path.basename(f["basis_dir"]))
+    assert sorted(x for x in os.listdir(d) if x.endswith(".pt") and not x.startswith("s-")) == [x for x in f["basis_files"] if x.endswith(".pt")]
+    print("uncond driver: worst relative U-Net input error", worst, "flipped", flipped)
+
+
+def test_sd_driver_matches_reference_driver_fixture(tmp_path, monkeypatch):
+    """Rows a10-a13, SD variant: EditStableDiffusion on the HIP engine against the reference's class driving a toy SD-style net with
+    fixed prompt embeddings / VAE stand-ins: inversion under the inversion prompt, forward under the forward prompt, guidance under
+    the edit prompt (edit.py:112-183, :385-502, :185-307)."""
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    from diffusion_pullback_amd import edit as E
+    from diffusion_pullback_amd import main as m
+    from oracle import unet_sd
+    f = load_golden("edit_sd_toy.pt")
+    a = f["args"]
+    cfg = unet_sd.SDConfig(**f["cfg"])
+    params = cf.sd_init_params(cfg, seed=f["seed"], gain=f["gain"], spectrum=cf.Spectrum(**f["spectrum"]))
+    net = _Rec(PullbackUNet("sd", cfg, params, dtype=torch.float32, device=DEV, max_batch=5, max_rank=2, verbose=False))
+    argv = ["--note", "t", "--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Examples", "--result_folder", str(tmp_path), "--device", DEV,
+            "--edit_prompt", "sitting dog", "--x_space_guidance_scale", str(a["x_space_guidance_scale"]), "--x_space_guidance_num_step",
+            str(a["x_space_guidance_num_step"]), "--x_space_guidance_edit_step", str(a["x_space_guidance_edit_step"]), "--edit_t", str(a["edit_t"]),
+            "--for_steps", str(a["for_steps"]), "--inv_steps", str(a["inv_steps"]), "--net_scale", "small", "--pca_rank", "2"]
+    args = m.preset(m.parse_args(argv))
+    args.input_root = os.path.join(str(tmp_path), "inputs")
+    args.image_size = 8
+    emb = f["emb"]
+
+    class VAE:
+        def encode(self, x): return (f["z0"] / 0.18215).to(DEV)
+        def decode(self, l): return l[:, :3]
+    saved = []
+    monkeypatch.setattr(E, "save_image", lambda x, path, nrow=None: saved.append((os.path.basename(path), x.detach().float().cpu().clone())))
+    ed = E.EditStableDiffusion(args, unet=net, vae=VAE(), prompt_encoder=lambda p: emb["edit"] if p == "tiger" else emb["for"], dataset={a["idx"]: torch.zeros(1, 3, 16, 16)})
+    ed.for_prompt_emb, ed.neg_prompt_emb, ed.null_prompt_emb, ed.inv_prompt_emb = (emb[k].to(DEV) for k in ("for", "neg", "null", "inv"))
+    assert torch.equal(ed.scheduler.alphas_cumprod, f["alphas_cumprod"]) and int(ed.edit_t_idx) == f["edit_t_idx"]
+    torch.manual_seed(a["rng_seed"])
+    res = ed.run_edit_local_encoder_pullback_zt(idx=a["idx"], op="mid", block_idx=0, vis_num=a["vis_num"], vis_num_pc=a["vis_num_pc"], pca_rank=a["pca_rank"], edit_prompt="tiger")
+    u, vT = ed.last_basis
+    assert (abs_cos_(vT, f["vT"]) > 0.999).all() and (abs_cos_(u.T, f["u"].T) > 0.999).all()
+    flipped = bool((vT[0].cpu() * f["vT"][0]).sum() < 0)
+    n_pre = (a["inv_steps"] - 2) + f["edit_t_idx"]
+    blk = a["x_space_guidance_num_step"] + (a["for_steps"] - 1 - f["edit_t_idx"])
+    worst = _compare_trace(net.calls, f, flipped, n_pre, blk, 2e-3)
+    ref_saved, got = dict(f["saved"]), dict(saved)
+    for tag, rtag in (("pos", "neg" if flipped else "pos"), ("neg", "pos" if flipped else "neg")):
+        n = f"x0_gen-Edit_zt-Examples_5-edit_0.7T-mid-block_0-pc_000_{tag}-edit_prompt_tiger.png"
+        assert rel(got[n], ref_saved[n.replace("_" + tag + "-", "_" + rtag + "-")]) < 2e-3
+    d = os.path.join(args.input_root, os.path.basename(f["basis_dir"]))
+    assert sorted(x for x in os.listdir(d) if x.endswith(".pt")) == [x for x in f["basis_files"] if x.endswith(".pt")]
+    assert len(res) == 2 and res[0].shape == (5, 4, 8, 8)
+    print("sd driver: worst relative U-Net input error", worst, "flipped", flipped)
+
+
+def abs_cos_(a, b):
+    from _util import abs_cos
+    return abs_cos(a, b)

@@ -1,10 +1,17 @@
-"""GPU parity at BASELINE.json's full sizes (SD-v1.5 4x64x64 -> mid 1280x8x8; CelebA-HQ DDPM 256x256 -> mid 512x8x8).
+"""GPU parity at BASELINE.json's full sizes (SD-v1.5 4x64x64 -> mid 1280x8x8 and every down / up tap; CelebA-HQ DDPM 256x256).
 
-Full-size oracle runs are expensive on CPU, so most checks are size-independent properties of the operator pair
-(J, J^T) the HIP engine implements -- adjointness <J v, u> = <v, J^T u>, linearity, orthonormality of the
-returned basis, fixed-point residual of the converged basis -- plus ONE oracle direction for JVP and VJP and a
-2-iteration oracle pullback, and the north-star criterion: bf16 top-5 singular vectors vs the fp32 path, |cos| >= 0.99
-(BASELINE.json; compared per vector where the spectrum separates them and as a subspace otherwise)."""
+Synthetic weights are spectrum-shaped (configs.Spectrum: sigma_1..12 of the mid-block Jacobian separated by >= 9 % each, above a
+flat bulk), so single singular vectors are well conditioned and the north-star criterion -- top-5 |cos| >= 0.99 of the 16-bit
+paths against fp32 on identical seeded inputs -- is asserted per vector with NO escape hatch.  Full-size oracle runs are
+expensive on the CPU, so they are computed once per module: one direction of primal / JVP / VJP at every tap (all three engine
+dtypes are compared against the same oracle vectors) and one 2-iteration k=5 oracle pullback.  The rest are size-independent
+properties of the operator pair (J, J^T): adjointness, linearity, orthonormality, convergence under the reference's stop rule.
+
+Tolerances (relative Frobenius error per pass vs the fp32 oracle): fp32 engine 5e-4, bf16 4e-2, fp16 1e-2.
+"""
+import functools
+import os
+
 import pytest
 import torch
 
@@ -12,17 +19,41 @@ from _util import abs_cos, oracle_jvp, oracle_vjp, rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+TOL = {torch.float32: 5e-4, torch.bfloat16: 4e-2, torch.float16: 1e-2}
+T_SD = 696.2727
+ENC = ("time_embedding", "conv_in", "down_blocks", "mid_block")
+TAPS = [("down", 0), ("down", 1), ("down", 2), ("down", 3), ("mid", 0), ("up", 0), ("up", 1), ("up", 2), ("up", 3)]
 
 
-def _sd15(dtype, k=5):
-    from diffusion_pullback_amd import PullbackUNet, configs as cf
-    enc = ("time_embedding", "conv_in", "down_blocks", "mid_block")
-    params = cf.sd_init_params(cf.SD15, seed=0, only_prefix=enc)
-    net = PullbackUNet("sd", cf.SD15, params, dtype=dtype, device=DEV, max_batch=1, max_rank=k, upto=("mid", 0), verbose=False)
+def _threads():
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+
+
+@functools.lru_cache(maxsize=None)
+def _sd15_params(full: bool):
+    from diffusion_pullback_amd import configs as cf
+    return cf.sd_init_params(cf.SD15, seed=0, only_prefix=None if full else ENC, spectrum=cf.Spectrum())
+
+
+@functools.lru_cache(maxsize=None)
+def _sd15_inputs():
     g = torch.Generator().manual_seed(0)
     ctx = torch.randn(1, 77, 768, generator=g)
     z = torch.randn(1, 4, 64, 64, generator=g)
-    return net, params, z, ctx, 696.2727
+    return z, ctx
+
+
+def _sd15(dtype, k=5, max_batch=1, full=False):
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    return PullbackUNet("sd", cf.SD15, _sd15_params(full), dtype=dtype, device=DEV, max_batch=max_batch, max_rank=k * max_batch,
+                        upto=("up", 3) if full else ("mid", 0), verbose=False)
+
+
+def _oracle_f(full, tap, ctx):
+    from diffusion_pullback_amd import configs as cf
+    from oracle import unet_sd
+    p = _sd15_params(full)
+    return lambda a: unet_sd.forward(p, cf.SD15, a, torch.tensor(T_SD), ctx.expand(a.shape[0], -1, -1), stop=tap)
 
 
 @pytest.fixture(scope="module")
@@ -30,11 +61,50 @@ def sd15_fp32():
     return _sd15(torch.float32)
 
 
+@pytest.fixture(scope="module")
+def oracle_taps():
+    """One direction of primal / JVP / VJP of the full SD-1.5 U-Net at every tap, fp32 CPU oracle (computed once)."""
+    _threads()
+    z, ctx = _sd15_inputs()
+    g = torch.Generator().manual_seed(2)
+    V = torch.randn(1, 16384, generator=g)
+    out = {}
+    for tap in TAPS:
+        f = _oracle_f(True, tap, ctx)
+        with torch.no_grad():
+            h = f(z)
+        U = torch.randn(1, h.numel(), generator=g)
+        out[tap] = dict(h=h, V=V, JV=oracle_jvp(f, z, V), U=U, JTU=oracle_vjp(f, z, U))
+    return out
+
+
+@pytest.fixture(scope="module")
+def oracle_pullback_k5():
+    """2 iterations of the reference algorithm (oracle.pullback, same autodiff calls as utils.py:766-799), k = 5, mid block."""
+    from oracle import pullback as opb
+    _threads()
+    z, ctx = _sd15_inputs()
+    k = 5
+    V0 = torch.linalg.qr(torch.randn(16384, k, generator=torch.Generator().manual_seed(0)))[0].T.contiguous()
+    u, s, vT = opb.pullback(_oracle_f(False, ("mid", 0), ctx), z, pca_rank=k, chunk_size=5, min_iter=0, max_iter=2, convergence_threshold=1e-9,
+                            variant="zt", V0=V0)
+    return dict(V0=V0, u=u, s=s, vT=vT)
+
+
+def _relfro_sv(s, vT, s_ref, vT_ref):
+    """relative Frobenius error of diag(s) vT after aligning each row's sign (singular vectors are defined up to sign)"""
+    a = (s[:, None] * vT).double().cpu()
+    b = (s_ref[:, None] * vT_ref).double().cpu()
+    sign = torch.sign((a * b).sum(-1, keepdim=True))
+    return ((a * sign - b).norm() / b.norm()).item()
+
+
+# ------------------------------------------------------------------------------------------------ operator properties
 def test_sd15_operator_properties_fp32(sd15_fp32):
-    net, _, z, ctx, t = sd15_fp32
+    z, ctx = _sd15_inputs()
     tap = ("mid", 0)
-    e = net.engine
-    e.primal(z, t, ctx, tap)
+    e = sd15_fp32.engine
+    e.primal(z, T_SD, ctx, tap)
     g = torch.Generator().manual_seed(1)
     V = torch.randn(3, 16384, generator=g).to(DEV)
     U = torch.randn(3, 81920, generator=g).to(DEV)
@@ -47,68 +117,116 @@ def test_sd15_operator_properties_fp32(sd15_fp32):
     assert rel(comb[0], 0.3 * JTU[0] - 1.7 * JTU[1]) < 2e-4          # linearity of the adjoint pass
 
 
-def test_sd15_one_direction_vs_oracle_fp32(sd15_fp32):
-    from diffusion_pullback_amd import configs as cf
-    from oracle import unet_sd
-    torch.set_num_threads(32)
-    net, params, z, ctx, t = sd15_fp32
-    tap = ("mid", 0)
-    f = lambda a: unet_sd.forward(params, cf.SD15, a, torch.tensor(t), ctx.expand(a.shape[0], -1, -1), stop=tap)
-    g = torch.Generator().manual_seed(2)
-    V = torch.randn(1, 16384, generator=g)
-    U = torch.randn(1, 81920, generator=g)
-    net.engine.primal(z, t, ctx, tap)
-    with torch.no_grad():
-        assert rel(net.engine.read(tap), f(z)) < 2e-4
-    assert rel(net.engine.jvp(tap, V.to(DEV)), oracle_jvp(f, z, V)) < 5e-4
-    assert rel(net.engine.vjp(tap, U.to(DEV)), oracle_vjp(f, z, U)) < 5e-4
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: every tap, every dtype
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_sd15_every_tap_one_direction_vs_oracle(dtype, oracle_taps):
+    """configs[4] (down / up block_0..3 sweep) + the mid tap: primal, JVP and VJP of one direction at FULL size against the fp32 CPU
+    oracle, in the engine's three dtypes.  In 16 bit this runs the fused L=4096 / 1024 / 256 attention kernels (head dim 40 / 80 / 160),
+    the halo-tile 3x3 convolutions at 64^2 / 32^2 / 16^2, the BK=64 ring GEMMs and the up-path UPCONV / concat ops at their real shapes."""
+    z, ctx = _sd15_inputs()
+    net = _sd15(dtype, k=1, full=True)
+    e = net.engine
+    tol = TOL[dtype]
+    errs = {}
+    for tap in TAPS:
+        o = oracle_taps[tap]
+        e.primal(z, T_SD, ctx, tap)
+        errs[tap] = (rel(e.read(tap), o["h"]), rel(e.jvp(tap, o["V"].to(DEV)), o["JV"]), rel(e.vjp(tap, o["U"].to(DEV)), o["JTU"]))
+    print(dtype, {k: tuple(round(x, 5) for x in v) for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not all(x < tol for x in v)}
+    assert not bad, f"(primal, jvp, vjp) relative errors over {tol}: {bad}"
 
 
-def test_sd15_pullback_two_iterations_vs_oracle(sd15_fp32):
-    from diffusion_pullback_amd import configs as cf
-    from oracle import pullback as opb
-    from oracle import unet_sd
-    torch.set_num_threads(32)
-    net, params, z, ctx, t = sd15_fp32
-    k = 2
-    V0 = torch.linalg.qr(torch.randn(16384, k, generator=torch.Generator().manual_seed(3)))[0].T.contiguous()
-    get_h = lambda zb: unet_sd.forward(params, cf.SD15, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=("mid", 0))
-    ur, sr, vr = opb.pullback(get_h, z, pca_rank=k, chunk_size=5, min_iter=0, max_iter=2, convergence_threshold=1e-9, variant="zt", V0=V0)
-    u, s, vT = net.local_encoder_pullback_zt(z, torch.tensor(t), ctx, op="mid", block_idx=0, pca_rank=k, chunk_size=5, min_iter=0, max_iter=2,
-                                             convergence_threshold=1e-9, V0=V0)
-    assert torch.allclose(s.cpu(), sr, rtol=1e-3), (s.cpu(), sr)
-    assert (abs_cos(vT, vr) > 0.9999).all(), abs_cos(vT, vr)
-    assert (abs_cos(u.T, ur.T) > 0.9999).all()
+# ------------------------------------------------------------------------------------------------ the algorithm vs the oracle
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_sd15_pullback_two_iterations_vs_oracle(dtype, oracle_pullback_k5):
+    """Same V0, same two iterations as the CPU oracle: per-vector |cos|, singular values and diag(s) vT."""
+    o = oracle_pullback_k5
+    z, ctx = _sd15_inputs()
+    net = _sd15(dtype)
+    u, s, vT = net.local_encoder_pullback_zt(z, torch.tensor(T_SD), ctx, op="mid", block_idx=0, pca_rank=5, chunk_size=5, min_iter=0, max_iter=2,
+                                             convergence_threshold=1e-9, V0=o["V0"])
+    cos_v, cos_u = abs_cos(vT, o["vT"]), abs_cos(u.T, o["u"].T)
+    fro = _relfro_sv(s.cpu(), vT.cpu(), o["s"], o["vT"])
+    print(dtype, "s", s.cpu().tolist(), "oracle", o["s"].tolist(), "|cos v|", cos_v.tolist(), "|cos u|", cos_u.tolist(), "relfro", fro)
+    if dtype == torch.float32:
+        assert torch.allclose(s.cpu(), o["s"], rtol=1e-3) and (cos_v > 0.9999).all() and (cos_u > 0.9999).all() and fro < 5e-3
+    else:
+        assert torch.allclose(s.cpu(), o["s"], rtol=2e-2), (s.cpu(), o["s"])
+        assert (cos_v > 0.99).all() and (cos_u > 0.99).all(), (cos_v, cos_u)
+        assert fro < 1e-1, fro
 
 
-def test_sd15_bf16_top5_vs_fp32(sd15_fp32):
-    """north star: top-5 singular vectors of the bf16 path vs the fp32 path on identical seeded inputs, 12 iterations."""
-    net32, _, z, ctx, t = sd15_fp32
-    net16 = _sd15(torch.bfloat16)[0]
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_sd15_16bit_top5_vs_fp32(dtype, sd15_fp32):
+    """NORTH STAR: top-5 singular vectors of the 16-bit path vs the fp32 path on identical seeded inputs after the reference's 12
+    iterations: |cos| >= 0.99 for EVERY vector, singular values to 1 %, diag(s) vT to 5 % -- on a spectrum whose gaps make
+    the per-vector comparison meaningful (asserted)."""
+    z, ctx = _sd15_inputs()
+    net16 = _sd15(dtype)
     k = 5
     V0 = torch.linalg.qr(torch.randn(16384, k, generator=torch.Generator().manual_seed(0)))[0].T.contiguous()
-    _, s32, v32, _ = net32.pullback_fixed(z, t, ctx, "mid", 0, k, 12, V0)
-    _, s16, v16, _ = net16.pullback_fixed(z, t, ctx, "mid", 0, k, 12, V0)
-    assert torch.allclose(s16, s32, rtol=2e-2), (s16, s32)
-    # orthonormal rows
-    assert torch.allclose((v16 @ v16.T).cpu(), torch.eye(k), atol=1e-3)
-    # subspace agreement (principal angles) and per-vector cosine
-    sv = torch.linalg.svdvals((v16 @ v32.T).double().cpu())
+    _, s32, v32, _ = sd15_fp32.pullback_fixed(z, T_SD, ctx, "mid", 0, k, 12, V0)
+    _, s16, v16, _ = net16.pullback_fixed(z, T_SD, ctx, "mid", 0, k, 12, V0)
+    ratios = (s32[1:] / s32[:-1]).cpu()
     cos = abs_cos(v16, v32)
-    print("sigma fp32", s32.cpu().tolist(), "bf16", s16.cpu().tolist(), "|cos|", cos.tolist(), "principal cos", sv.tolist())
-    gaps = (s32[:-1] - s32[1:]).abs() / s32[:-1]
-    if float(gaps.min()) > 0.02:                       # well separated spectrum: per-vector criterion
-        assert (cos > 0.99).all(), cos
-    assert sv.min() > 0.99 or float(gaps.min()) <= 0.02, sv
+    fro = _relfro_sv(s16.cpu(), v16.cpu(), s32.cpu(), v32.cpu())
+    print(dtype, "sigma fp32", s32.cpu().tolist(), "16-bit", s16.cpu().tolist(), "|cos|", cos.tolist(), "relfro", fro)
+    assert (ratios < 0.95).all(), f"spectrum not separated: {s32.cpu().tolist()}"        # the criterion below is well conditioned
+    assert (cos > 0.99).all(), cos
+    assert torch.allclose(s16, s32, rtol=1e-2), (s16, s32)
+    assert fro < 5e-2, fro
+    assert torch.allclose((v16 @ v16.T).cpu(), torch.eye(k), atol=1e-3)                   # orthonormal rows
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_sd15_converges_under_reference_stop_rule(dtype):
+    """utils.py:803-808 with the reference's defaults (min_iter 10, max_iter 100, atol 1e-3): the shaped spectrum converges at the
+    earliest iteration the rule allows (i > min_iter -> 12 iterations), in fp32 and with bf16 rounding noise."""
+    z, ctx = _sd15_inputs()
+    net = _sd15(dtype)
+    V0 = torch.linalg.qr(torch.randn(16384, 5, generator=torch.Generator().manual_seed(0)))[0].T.contiguous()
+    net.local_encoder_pullback_zt(z, torch.tensor(T_SD), ctx, op="mid", block_idx=0, pca_rank=5, V0=V0)
+    print(dtype, "iterations", net.last_iters, "dist", net.last_dist)
+    assert net.last_iters == 12, (net.last_iters, net.last_dist)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[3]
+def test_sd15_config3_k10_samples_advanced_together():
+    """configs[3]: edit-prompt context, k = 10, several x_t samples advanced together on one GPU (one rank's share of the 64-sample
+    job): the batched run equals one-at-a-time runs, and one of the ten tangents equals the oracle JVP of that direction."""
+    _threads()
+    _, ctx0 = _sd15_inputs()
+    k, S, iters = 10, 4, 6
+    g = torch.Generator().manual_seed(77)
+    ctx = torch.randn(1, 77, 768, generator=g)                                   # seeded "edit prompt" embedding (not the null ctx)
+    zs = torch.randn(S, 4, 64, 64, generator=g)
+    V0 = torch.linalg.qr(torch.randn(16384, k, generator=g))[0].T.contiguous()
+    net = _sd15(torch.bfloat16, k=k, max_batch=S)
+    _, s_b, V_b, _ = net.pullback_fixed(zs, T_SD, ctx.expand(S, -1, -1), "mid", 0, k, iters, V0)
+    s_b, V_b = s_b.clone(), V_b.clone()
+    for i in range(S):
+        _, s_i, V_i, _ = net.pullback_fixed(zs[i:i + 1], T_SD, ctx, "mid", 0, k, iters, V0)
+        cos = abs_cos(V_b[k * i:k * (i + 1)], V_i)
+        assert torch.allclose(s_b[k * i:k * (i + 1)], s_i, rtol=2e-2), (i, s_b[k * i:k * (i + 1)], s_i)
+        assert (cos > 0.99).all(), (i, cos)                                       # bf16 atomics in GroupNorm: not bitwise repeatable
+    # distinct samples have distinct bases (the batch is not one sample repeated)
+    assert abs_cos(V_b[0:1], V_b[k:k + 1]).item() < 0.99
+    e = net.engine
+    e.primal(zs[0:1], T_SD, ctx, ("mid", 0))
+    U = e.jvp(("mid", 0), V0.to(DEV))                                             # nt = 10 tangents in one pass
+    f = _oracle_f(False, ("mid", 0), ctx)
+    assert rel(U[7:8], oracle_jvp(f, zs[0:1], V0[7:8])) < TOL[torch.bfloat16]
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[1]
 def test_ddpm256_operator_and_oracle_fp32():
     from diffusion_pullback_amd import PullbackUNet, configs as cf
     from oracle import unet_ddpm
-    torch.set_num_threads(32)
+    _threads()
     cfg = cf.CELEBA_HQ_256
-    params = cf.ddpm_init_params(cfg, seed=0)
-    net = PullbackUNet("ddpm", cfg, params, dtype=torch.float32, device=DEV, max_batch=1, max_rank=3, upto=("mid", 0), verbose=False)
+    params = cf.ddpm_init_params(cfg, seed=0, spectrum=cf.Spectrum())
+    net = PullbackUNet("ddpm", cfg, params, dtype=torch.float32, device=DEV, max_batch=1, max_rank=5, upto=("mid", 0), verbose=False)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 3, 256, 256, generator=g)
     t = 600.0
@@ -124,3 +242,7 @@ def test_ddpm256_operator_and_oracle_fp32():
         assert rel(e.read(tap), f(x)) < 2e-4
     assert rel(JV[:1], oracle_jvp(f, x, V[:1].cpu())) < 5e-4
     assert rel(JTU[:1], oracle_vjp(f, x, U[:1].cpu())) < 5e-4
+    # configs[1]: k = 5 under the reference's stop rule converges at the earliest allowed iteration on the shaped spectrum
+    V0 = torch.linalg.qr(torch.randn(196608, 5, generator=g))[0].T.contiguous()
+    u, s, vT = net.local_encoder_pullback_xt(x, torch.tensor(t), op="mid", block_idx=0, pca_rank=5, V0=V0)
+    assert net.last_iters == 12 and ((s[1:] / s[:-1]) < 0.95).all(), (net.last_iters, s)

@@ -1,8 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path behind the C ABI vs the CPU oracle.
 
 Tolerances: fp32 engine vs fp32 oracle -- relative Frobenius error <= 2e-4 per pass (different
-accumulation order only); bf16 engine vs fp32 oracle -- <= 4e-2 per pass, top singular vectors
-|cos| >= 0.99 (BASELINE.json north_star)."""
+accumulation order only); bf16 engine vs fp32 oracle -- <= 4e-2 per pass (8-bit significand), fp16 engine -- <= 1e-2 per pass
+(11-bit significand); top singular vectors |cos| >= 0.99 (BASELINE.json north_star)."""
 import ctypes as C
 
 import pytest
@@ -12,7 +12,7 @@ from _util import abs_cos, load_golden, oracle_jvp, oracle_vjp, rel
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2, torch.float16: 1e-2}
 
 
 def _dev():
@@ -59,7 +59,7 @@ def check_passes(net, fwd, x, t, ctx, taps, dtype, k=3, seed=0, report=None):
     return errs
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_toy_sd_primal_jvp_vjp(dtype):
     from diffusion_pullback_amd import PullbackUNet
     from oracle import unet_sd
@@ -69,7 +69,7 @@ def test_toy_sd_primal_jvp_vjp(dtype):
     check_passes(net, fwd, f["z"], float(f["t"]), f["ctx"], [("down", 0), ("down", 1), ("mid", 0), ("up", 0), ("up", 1), "eps"], dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_small_ddpm_primal_jvp_vjp(dtype):
     from diffusion_pullback_amd import PullbackUNet
     from oracle import unet_ddpm
@@ -81,7 +81,7 @@ def test_small_ddpm_primal_jvp_vjp(dtype):
 
 
 @pytest.mark.parametrize("dtype,boc,size", [(torch.float32, (320, 640), 32), (torch.bfloat16, (320, 640), 32), (torch.bfloat16, (640, 640), 32),
-                                            (torch.bfloat16, (1280, 1280), 16)])
+                                            (torch.bfloat16, (1280, 1280), 16), (torch.float16, (320, 640), 32), (torch.float16, (1280, 1280), 16)])
 def test_medium_sd_shapes(dtype, boc, size):
     """SD-like widths with the real head dims (40/80/160), 77-token context (padded to 80), 128x128 GEMM tiles; in bf16 the
     L=1024 (head dim 40, 80) and L=256 (head dim 160) self-attention layers run the fused tangent/adjoint attention kernels."""
@@ -239,3 +239,98 @@ def test_batched_samples_match_single_sample_runs():
         _, s_i, V_i, _ = net.pullback_fixed(zs[i:i + 1], f["t"], ctxs[i:i + 1], "mid", 0, 3, 4, V0)
         assert torch.allclose(s_b[3 * i:3 * i + 3], s_i, rtol=1e-4), (i, s_b, s_i)
         assert (abs_cos(V_b[3 * i:3 * i + 3], V_i) > 0.9999).all()
+
+
+def test_medium_sd21_shapes():
+    """SD-2.x layer shapes: 64-wide heads at every level (5 / 10 heads), 1024-wide context, Linear proj_in / proj_out; the L = 1024
+    self-attention runs the fused head-dim-64 kernels in 16 bit."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(5, 10), cross_dim=1024, sample_size=32, ctx_len=77, use_linear_projection=True)
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 4, 32, 32, generator=g); ctx = torch.randn(1, 77, 1024, generator=g); t = torch.tensor(696.2727)
+    fwd = lambda a, tap: unet_sd.forward(p, cfg, a, t, ctx.expand(a.shape[0], -1, -1), stop=tap)
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=1, max_rank=4, upto=("mid", 0), verbose=False)
+        print(dtype, check_passes(net, fwd, z, float(t), ctx, [("down", 0), ("mid", 0)], dtype, k=2))
+
+
+def test_context_shape_is_validated_and_unpadded_width_works():
+    """encoder_hidden_states with the wrong token count / width raises instead of reading out of bounds; a context width that is
+    not a multiple of 8 is zero-padded at the boundary."""
+    from diffusion_pullback_amd import DpbError, PullbackUNet
+    from oracle import unet_sd
+    cfg = unet_sd.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(2, 2),
+                           cross_dim=20, groups=8, sample_size=8, ctx_len=5)
+    p = unet_sd.init_params(cfg, seed=4)
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(1, 4, 8, 8, generator=g); ctx = torch.randn(1, 5, 20, generator=g); t = torch.tensor(500.0)
+    net = PullbackUNet("sd", cfg, p, dtype=torch.float32, device=_dev(), max_batch=2, max_rank=4, verbose=False)
+    fwd = lambda a, tap: unet_sd.forward(p, cfg, a, t, ctx.expand(a.shape[0], -1, -1), stop=None if tap == "eps" else tap)
+    check_passes(net, fwd, z, float(t), ctx, [("mid", 0), "eps"], torch.float32, k=2)
+    for bad in (torch.randn(1, 4, 20), torch.randn(1, 5, 24), torch.randn(3, 5, 20), torch.randn(5, 20)):
+        with pytest.raises(DpbError):
+            net.get_h(z, t, bad, op="mid", block_idx=0)
+    with pytest.raises(DpbError):
+        net.get_h(z, t, None, op="mid", block_idx=0)
+
+
+def test_v0_none_draw_matches_reference_rng():
+    """Row a3: with V0=None the product draws QR(randn(N, k)) on the CPU generator exactly as the reference does on a CPU device
+    (utils.py:750-753 / :194-197), so seeding torch reproduces the reference's own run, basis and all."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_ddpm
+    f = load_golden("pullback_xt_ddpm.pt")
+    cfg = unet_ddpm.DDPMConfig(**f["cfg"])
+    net = PullbackUNet("ddpm", cfg, unet_ddpm.init_params(cfg, seed=f["seed"]), dtype=torch.float32, device=_dev(), max_batch=1, max_rank=4, verbose=False)
+    torch.manual_seed(f["rng_seed"])
+    u, s, vT = net.local_encoder_pullback_xt(f["x"], f["t"], op="mid", block_idx=0, pca_rank=f["k"], chunk_size=f["chunk_size"],
+                                             min_iter=f["min_iter"], max_iter=f["max_iter"], convergence_threshold=f["thr"])
+    assert torch.allclose(s.cpu(), f["s"], rtol=2e-3), (s.cpu(), f["s"])
+    assert (abs_cos(vT, f["vT"]) > 0.999).all() and (abs_cos(u.T, f["u"].T) > 0.999).all()
+    fz, cfgz, pz = _toy_sd()
+    c = fz["cases"][0]
+    netz = PullbackUNet("sd", cfgz, pz, dtype=torch.float32, device=_dev(), max_batch=1, max_rank=8, verbose=False)
+    torch.manual_seed(c["rng_seed"])
+    u, s, vT = netz.local_encoder_pullback_zt(fz["z"], fz["t"], fz["ctx"], op=c["op"], block_idx=c["idx"], pca_rank=c["k"], chunk_size=c["chunk"],
+                                              min_iter=c["min_iter"], max_iter=c["max_iter"], convergence_threshold=c["thr"])
+    assert torch.allclose(s.cpu(), c["zt"][1], rtol=2e-3) and (abs_cos(vT, c["zt"][2]) > 0.999).all()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_stop_rule_iteration_count_and_history(case):
+    """Row a7 (utils.py:803-808).  The product signs every singular vector for non-negative overlap with the previous iterate; the
+    reference takes LAPACK's arbitrary sign, which on a CPU run flips vectors between iterations (recorded dists ~ 2 per flipped
+    vector, tests/golden/pullback_history.pt) so its allclose test only fires when the signs happen to coincide.  Pinned here: the
+    product's per-iteration dist and its stopping iteration equal the oracle's SIGN-ALIGNED history (the oracle reproduces the
+    reference's prints, test_oracle.py); the reference's own count can only be later."""
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    from oracle import pullback as opb
+    from oracle import unet_sd
+    f = load_golden("pullback_history.pt")
+    c = f["cases"][case]
+    cfg = unet_sd.SDConfig(**f["cfg"])
+    p = cf.sd_init_params(cfg, seed=f["seed"], gain=f["gain"], spectrum=cf.Spectrum(**c["spectrum"]) if c["spectrum"] else None)
+    get_h = lambda zb: unet_sd.forward(p, cfg, zb, f["t"], f["ctx"].expand(zb.shape[0], -1, -1), stop=("mid", 0))
+    *_, h = opb.pullback(get_h, f["z"], pca_rank=c["k"], chunk_size=5, min_iter=c["min_iter"], max_iter=c["max_iter"], convergence_threshold=c["thr"],
+                         variant="zt", V0=c["V0"], history=True)
+    prev, dists, stop = c["V0"], [], None
+    for i, V in enumerate(h["V"]):
+        V = V * torch.sign((V * prev).sum(-1, keepdim=True))                # sign-aligned iterate
+        dists.append(torch.dist(prev, V).item())
+        if stop is None and torch.allclose(prev, V, atol=c["thr"]) and i > c["min_iter"]:
+            stop = i + 1
+        prev = V
+    expected_iters = stop if stop is not None else c["max_iter"]
+    net = PullbackUNet("sd", cfg, p, dtype=torch.float32, device=_dev(), max_batch=1, max_rank=8, verbose=False)
+    net.local_encoder_pullback_zt(f["z"], f["t"], f["ctx"], op="mid", block_idx=0, pca_rank=c["k"], chunk_size=5, min_iter=c["min_iter"],
+                                  max_iter=c["max_iter"], convergence_threshold=c["thr"], V0=c["V0"])
+    print("case", case, "product iters", net.last_iters, "aligned-oracle", expected_iters, "reference", c["iters"], "dists", net.last_history[-3:])
+    assert net.last_iters == expected_iters, (net.last_iters, expected_iters)
+    assert c["iters"] >= net.last_iters                                      # the reference needs a sign coincidence on top
+    n = net.last_iters
+    torch.testing.assert_close(torch.tensor(net.last_history), torch.tensor(dists[:n]), rtol=5e-2, atol=2e-4)
+    if case == 0:
+        assert stop is not None and stop < c["max_iter"] and not c["converged"]    # converges here, while the reference ran to max_iter
