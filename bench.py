@@ -1,20 +1,26 @@
 #!/usr/bin/env python
 """Headline benchmark: pullback top-k SVD power iterations / second (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                               # BASELINE configs[2], weak scaling
+    python bench.py --gpus N --samples 64 --k 10 --ctx edit --samples-per-gpu 8   # BASELINE configs[3], strong scaling
 
-A *step* is one power iteration for k directions on one x_t sample: k JVPs + k VJPs through the
-U-Net prefix up to the tap + the k x N re-orthonormalisation (reference src/utils/utils.py:756-808).
-A sample's job is one primal (stash) pass + ITERS_PER_SAMPLE=12 iterations (= min_iter+2, the
-reference's minimum and what its Colab log ran); the primal pass of every sample started inside the
-timed region is timed too.  Inputs (x_t, ctx, V0) are resident in HBM before the clock starts.
+A *step* is one power iteration for k directions on one x_t sample: k JVPs + k VJPs through the U-Net prefix up to the
+tap + the k x N re-orthonormalisation (reference src/utils/utils.py:756-808).  A sample's job is one primal (stash) pass
++ ITERS_PER_SAMPLE = 12 iterations (= min_iter + 2, the reference's minimum and what its Colab log ran); the primal pass
+of every sample started inside the timed region is timed too.  Inputs (x_t, ctx, V0) are resident in HBM before the
+clock starts.  Weights are the seeded synthetic ones with the shaped spectrum (configs.Spectrum): the top singular values
+are separated, so the reference's own stop rule converges (reported as `time_to_converged_basis`).
 
-N>1: one process per GPU (torchrun), independent samples per rank (weak scaling, no data-path
-collective), one RCCL all_gather of the final bases (u, s, vT) inside the timed region.
+N > 1: one process per GPU (torchrun), samples dealt to ranks, no collective inside the iterations, ONE packed RCCL
+all_gather of the final bases (dist.gather_bases) inside the timed region.
+  * default (weak): every rank runs the same per-GPU job on its own samples -- value = N * K / max-over-ranks time;
+  * --samples T (strong): T samples in total (seeds 0..T-1), sample i on rank i mod N (dist.shard_indices), the whole job is
+    T * 12 steps -- value = T * 12 / max-over-ranks time, "scaling": "strong" (the north star's 64-sample config).
 
-Output: ONE JSON line on rank 0 with `roofline` (dominant kernel = the 128x128 MFMA GEMM, measured live
-with HIP events around every launch in a separate instrumented iteration) and `cpu_baseline` (the CPU
-oracle, i.e. the reference's algorithm with the same autodiff calls, timed on this host's cores).
+Output: ONE JSON line on rank 0 with `roofline` (dominant kernel = most GPU time, measured live with HIP events around
+every GEMM launch on the engine's stream in a separate instrumented iteration) and `cpu_baseline` (the CPU oracle, i.e.
+the reference's algorithm with the same autodiff calls, BASELINE.md section 3 protocol: 1 warm-up + 2 timed iterations on
+this host's cores, CPU model stated).
 """
 import argparse
 import json
@@ -28,8 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ITERS_PER_SAMPLE = 12
-PEAK = {"bf16": 2500.0, "fp32": 157.3}      # TFLOP/s dense MFMA (MI355X_MICROARCH.md)
-MAC_G = {"sd15": 130.72, "ddpm256": 67.58}  # GMAC of one get_h(mid) forward
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # TFLOP/s dense MFMA (MI355X_MICROARCH.md)
+MAC_G = {"sd15": 130.72, "ddpm256": 67.58}                 # GMAC of one get_h(mid) forward
+TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def parse():
@@ -38,48 +45,78 @@ def parse():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--workload", default="sd15", choices=["sd15", "ddpm256", "toy"])
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--k", type=int, default=5)
-    ap.add_argument("--op", default="mid", choices=["down", "mid", "up"], help="feature tap (BASELINE config 5 sweeps down/up 0..3)")
+    ap.add_argument("--op", default="mid", choices=["down", "mid", "up"], help="feature tap (BASELINE configs[4] sweeps down/up 0..3)")
     ap.add_argument("--block-idx", type=int, default=0)
     ap.add_argument("--samples-per-gpu", type=int, default=1,
-                    help="x_t samples advanced together per GPU (independent bases, shared weight stream); steps must be a multiple")
+                    help="x_t samples advanced together per GPU (independent bases, shared weight stream); weak mode: steps must be a multiple")
+    ap.add_argument("--samples", type=int, default=0,
+                    help="strong-scaling mode (BASELINE configs[3]): total number of x_t samples sharded over the ranks; steps = samples * 12")
+    ap.add_argument("--ctx", default="null", choices=["null", "edit"], help="SD conditioning: seeded null-prompt or edit-prompt embedding")
+    ap.add_argument("--flat-spectrum", action="store_true", help="unshaped random-init weights (round-1 workload; the stop rule does not converge)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-k", type=int, default=0, help="directions in the bounded CPU sample (0 = all k: one full power iteration, ~20 s)")
+    ap.add_argument("--cpu-k", type=int, default=0, help="directions per CPU iteration (0 = all k)")
+    ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU power iterations after the warm-up (BASELINE.md section 3: 2)")
     return ap.parse_args()
 
 
-def make_workload(name, dtype, device, k, spg, tap=("mid", 0)):
-    """-> (net, get_h_oracle, samples x [S,...], t, ctx, V0[k,N], tap)"""
+def make_workload(name, dtype, device, k, spg, tap=("mid", 0), ctx_kind="null", shaped=True):
+    """-> (net, get_h_oracle, sample shape, t, ctx[1,L,D] or None, V0[k,N])"""
     from diffusion_pullback_amd import PullbackUNet
+    from diffusion_pullback_amd import configs as cf
     g = torch.Generator().manual_seed(0)
+    sp = cf.Spectrum() if shaped else None
     if name == "sd15" or name == "toy":
-        from diffusion_pullback_amd import configs as cf
         cfg = cf.SD15 if name == "sd15" else cf.SDConfig(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False),
-                                                                  up_attn=(False, True), heads=(2, 2), cross_dim=64, sample_size=16, ctx_len=77)
+                                                          up_attn=(False, True), heads=(2, 2), cross_dim=64, sample_size=16, ctx_len=77)
         enc = ("time_embedding", "conv_in", "down_blocks", "mid_block") if tap[0] != "up" else None
-        params = cf.sd_init_params(cfg, seed=0, only_prefix=enc)
+        params = cf.sd_init_params(cfg, seed=0, only_prefix=enc, spectrum=sp)
         net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=tap, verbose=False)
         t = 696.2727
         ctx = torch.randn(1, cfg.ctx_len, cfg.cross_dim, generator=g)          # fixed seeded "null" embedding
+        if ctx_kind == "edit":                                                   # a different seeded embedding standing for the edit prompt
+            ctx = torch.randn(1, cfg.ctx_len, cfg.cross_dim, generator=torch.Generator().manual_seed(4242))
         shape = (cfg.in_channels, cfg.sample_size, cfg.sample_size)
+
         def oracle_get_h(zb):      # cpu_baseline leg only
             from oracle import unet_sd
             return unet_sd.forward(params, cfg, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=tap)
     else:
-        from diffusion_pullback_amd import configs as cf
         cfg = cf.CELEBA_HQ_256
-        params = cf.ddpm_init_params(cfg, seed=0)
+        params = cf.ddpm_init_params(cfg, seed=0, spectrum=sp)
         net = PullbackUNet("ddpm", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=tap, verbose=False)
         t, ctx = 600.0, None
         shape = (cfg.in_channels, cfg.resolution, cfg.resolution)
+
         def oracle_get_h(xb):      # cpu_baseline leg only
             from oracle import unet_ddpm
             return unet_ddpm.forward(params, cfg, xb, torch.tensor(t), stop=tap)
     n_in = shape[0] * shape[1] * shape[2]
     V0 = torch.linalg.qr(torch.randn(n_in, k, generator=g))[0].T.contiguous()
     return net, oracle_get_h, shape, t, ctx, V0
+
+
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, logical, (len(phys) or logical)
 
 
 def main():
@@ -91,53 +128,80 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:        # launched by torchrun (also at N = 1: the RCCL path runs at world_size 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from diffusion_pullback_amd import dist as pdist
     dname = a.dtype or ("fp32" if a.workload == "ddpm256" else "bf16")
-    dtype = torch.float32 if dname == "fp32" else torch.bfloat16
+    dtype = TORCH_DTYPE[dname]
     k = a.k
     S = a.samples_per_gpu
-    assert a.steps % S == 0 and a.warmup % S == 0, "--steps and --warmup must be multiples of --samples-per-gpu"
+    strong = a.samples > 0
     tap = (a.op, a.block_idx)
-    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, S, tap)
+    net, oracle_get_h, shape, t, ctx, V0 = make_workload(a.workload, dtype, dev, k, S, tap, a.ctx, not a.flat_spectrum)
     eng = net.engine
+    n_in, n_h = eng.n_in, eng.tap_numel(tap)
 
-    group = S * ITERS_PER_SAMPLE                      # steps per group of S concurrently advanced samples
-    n_groups = (a.steps + group - 1) // group
-    n_warm = (a.warmup + group - 1) // group if a.warmup > 0 else 0
-    n_samples = n_groups * S
-    gx = torch.Generator().manual_seed(1000 + rank)
-    xs = torch.randn(max(n_groups, n_warm, 1) * S, *shape, generator=gx).to(dev)   # synthetic latents, resident in HBM
+    if strong:
+        mine = pdist.shard_indices(a.samples, rank, world)          # sample i -> rank i mod world
+        steps = a.samples * ITERS_PER_SAMPLE
+        xs = torch.stack([torch.randn(*shape, generator=torch.Generator().manual_seed(1000 + i)) for i in mine]).to(dev) if mine else None
+        groups = [list(range(j, min(j + S, len(mine)))) for j in range(0, len(mine), S)]     # ragged last group allowed
+        n_samples = len(mine)
+    else:
+        assert a.steps % S == 0 and a.warmup % S == 0, "--steps and --warmup must be multiples of --samples-per-gpu"
+        steps = a.steps
+        group = S * ITERS_PER_SAMPLE                      # steps per group of S concurrently advanced samples
+        n_groups = (a.steps + group - 1) // group
+        n_warm = (a.warmup + group - 1) // group if a.warmup > 0 else 0
+        n_samples = n_groups * S
+        gx = torch.Generator().manual_seed(1000 + rank)
+        xs = torch.randn(max(n_groups, n_warm, 1) * S, *shape, generator=gx).to(dev)   # synthetic latents, resident in HBM
     ctx_d = ctx.to(dev).expand(S, -1, -1).contiguous() if ctx is not None else None
     V0_d = V0.to(dev).repeat(S, 1).contiguous()           # same seeded V0 for every sample
 
-    def run(steps, xs_):
-        out = None
-        done = 0
-        gi = 0
-        while done < steps:
-            n = min(ITERS_PER_SAMPLE, (steps - done) // S)
+    def run_weak(nsteps, xs_):
+        done, gi, res = 0, 0, {}
+        while done < nsteps:
+            n = min(ITERS_PER_SAMPLE, (nsteps - done) // S)
             eng.primal(xs_[gi * S:(gi + 1) * S], t, ctx_d, tap)
-            V = V0_d.clone()
-            out = eng.iterate(tap, V, n)
+            V, U, s, _ = eng.iterate(tap, V0_d.clone(), n)
+            for j in range(S):                            # global sample id: this rank's gi-th group
+                res[(gi * S + j) * world + rank] = (U[j * k:(j + 1) * k].T, s[j * k:(j + 1) * k], V[j * k:(j + 1) * k])
             done += n * S
             gi += 1
-        return out
+        return res
 
-    if a.warmup > 0:
-        run(a.warmup, xs)
+    def run_strong():
+        res = {}
+        for grp in groups:
+            b = len(grp)
+            eng.primal(xs[grp[0]:grp[0] + b], t, None if ctx_d is None else ctx_d[:b], tap)
+            V, U, s, _ = eng.iterate(tap, V0_d[:b * k].clone(), ITERS_PER_SAMPLE)
+            for j, li in enumerate(grp):
+                res[mine[li]] = (U[j * k:(j + 1) * k].T, s[j * k:(j + 1) * k], V[j * k:(j + 1) * k])
+        return res
+
+    if a.warmup > 0:                                      # untimed: page in the kernels, weights and the allocator
+        if strong:
+            if groups:
+                eng.primal(xs[:len(groups[0])], t, None if ctx_d is None else ctx_d[:len(groups[0])], tap)
+                eng.iterate(tap, V0_d[:len(groups[0]) * k].clone(), min(ITERS_PER_SAMPLE, max(1, a.warmup)))
+        else:
+            run_weak(a.warmup, xs)
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    V, U, s, conv = run(a.steps, xs)
-    if dist:   # final basis gather (the only collective of the path)
-        for ten in (U, s, V):
-            buf = [torch.empty_like(ten) for _ in range(world)]
-            dist.all_gather(buf, ten.contiguous())
+    local_res = run_strong() if strong else run_weak(steps, xs)
+    n_total = a.samples if strong else n_samples * world
+    if dist:   # final basis gather: the only collective of the path, ONE packed all_gather (RCCL over xGMI)
+        allres = pdist.gather_bases(local_res, n_total)
+    else:
+        allres = local_res
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -147,29 +211,38 @@ def main():
         td = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
         dt = td.item()
-    finite = bool(torch.isfinite(s).all() and torch.isfinite(V).all())
+    assert len(allres) == n_total, (len(allres), n_total)
+    s0 = allres[0][1]
+    finite = all(bool(torch.isfinite(v[1]).all() and torch.isfinite(v[2]).all()) for v in allres.values())
 
+    total_steps = steps if strong else world * steps
     res = {
         "metric": "pullback top-k SVD iters/sec (SD-v1.5 mid-block, 4x64x64)" if a.workload == "sd15" else f"pullback top-k SVD iters/sec ({a.workload} mid-block)",
-        "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dname, "data": "synthetic (seeded random-init weights at the exact architecture shapes, randn latents)",
-        "config": {"workload": {"sd15": "BASELINE configs[2]: SD-v1.5 4x64x64 latent, no edit prompt (seeded null ctx[1,77,768]), mid-block h[1280,8,8], t=696.27",
+        "value": total_steps / dt, "unit": "iters/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / (steps if not strong else max(1, len(mine) * ITERS_PER_SAMPLE)), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": dname, "data": "synthetic (seeded random-init weights at the exact architecture shapes with a shaped spectrum, randn latents)",
+        "config": {"workload": {"sd15": ("BASELINE configs[3]: SD-v1.5 4x64x64 latents, edit-prompt ctx[1,77,768], mid-block, samples sharded over the GPUs" if strong else
+                                         "BASELINE configs[2]: SD-v1.5 4x64x64 latent, no edit prompt (seeded null ctx[1,77,768]), mid-block h[1280,8,8], t=696.27"),
                                 "ddpm256": "BASELINE configs[1]: CelebA-HQ DDPM 256x256 x[3,256,256], mid-block h[512,8,8], t=600",
                                 "toy": "toy SD-style net (plumbing check)"}[a.workload],
-                   "tap": list(tap), "pca_rank": k, "iters_per_sample": ITERS_PER_SAMPLE, "samples_timed_per_gpu": n_samples, "samples_advanced_together": S,
-                   "parallelism": f"{world} x independent samples, final all_gather of (u,s,vT)" if world > 1 else "single GPU"},
-        "finite": finite, "s_top": [round(v, 5) for v in s.cpu().tolist()[:k]],
+                   "tap": list(tap), "pca_rank": k, "ctx": a.ctx, "iters_per_sample": ITERS_PER_SAMPLE, "samples_total": n_total,
+                   "samples_this_rank": n_samples, "samples_advanced_together": S, "spectrum": "flat" if a.flat_spectrum else "shaped (configs.Spectrum())",
+                   "parallelism": (f"{world} ranks (RCCL world_size {world}), sample i on rank i mod {world}, one packed all_gather of (u,s,vT)" if dist
+                                   else "single process, no collective"),
+                   "rccl_world_size": world if dist else 0},
+        "finite": finite, "s_top": [round(v, 4) for v in s0.cpu().tolist()[:k]],
     }
 
     if rank == 0 and not a.no_roofline:
         # ---- roofline leg: one instrumented iteration, HIP events around every GEMM launch on the engine stream
-        eng.primal(xs[0:S], t, ctx_d, tap)
+        x1 = xs[0:S] if xs is not None and xs.shape[0] >= S else torch.randn(S, *shape).to(dev)
+        eng.primal(x1, t, ctx_d, tap)
         eng.profile(True)
         eng.iterate(tap, V0_d.clone(), 1)
         if os.environ.get("DPB_PROFILE_CSV"):
             eng.profile_dump(os.environ["DPB_PROFILE_CSV"])
-        tname = "float" if dname == "fp32" else "bf16"
+        tname = "float" if dname == "fp32" else dname.replace("fp16", "f16")
         kinds = {"gemm_kernel<%s,64,64,4>" % tname: eng.profile_read(0), "gemm_kernel<%s,128,128,4>" % tname: eng.profile_read(1),
                  "gemm_dma_kernel<128,128,3> / <256,128,3>": eng.profile_read(2), "gemm_dma_kernel<64,64,4>": eng.profile_read(3),
                  "gemm_ring64_kernel<128,128,2>": eng.profile_read(4), "conv_halo_kernel": eng.profile_read(5)}
@@ -179,47 +252,82 @@ def main():
         ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
         mac = MAC_G.get(a.workload) if tap == ("mid", 0) else None
         gemm_ms = sum(v[1] for v in kinds.values())
-        traffic = None                                                  # HBM bytes per launch of the dominant kernel from the committed PMC passes
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_sd15_mid_k5_bf16.json")
-        if a.workload == "sd15" and dname == "bf16" and S == 1 and os.path.exists(pmc):
-            ent = json.load(open(pmc))["kernels"].get(dom)
-            if ent and ent.get("write_kb_per_launch") is not None:
-                traffic = (2.0 * ent["fetch_kb_per_launch"] + ent["write_kb_per_launch"]) * 1024.0
+        traffic, tsrc = None, None                                       # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_sd15_mid_k5_bf16.json")
+            if a.workload == "sd15" and dname == "bf16" and S == 1 and k == 5 and tap == ("mid", 0) and os.path.exists(pmc):
+                ent = json.load(open(pmc))["kernels"].get(dom)
+                if ent and ent.get("write_kb_per_launch") is not None:
+                    traffic = (2.0 * ent["fetch_kb_per_launch"] + ent["write_kb_per_launch"]) * 1024.0
+                    tsrc = os.path.basename(pmc)
+                    break
+        ms_step = 1e3 * dt / (steps if not strong else max(1, len(mine) * ITERS_PER_SAMPLE))
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach / PEAK[dname],
-                           "traffic": traffic, "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic_*.json)", "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
+                           "traffic": traffic, "traffic_note": f"HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{tsrc})",
+                           "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
                            "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * v[1] / max(v[0], 1),
                                                     "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},
-                           "gemm_time_share_of_step": gemm_ms / (res["ms_per_step"] * S),
+                           "gemm_time_share_of_step": gemm_ms / (ms_step * S),
                            "algorithmic_flops_per_step": 2 * k * 2 * mac * 1e9 if mac else None,
-                           "whole_step_frac_of_peak": (2 * k * 2 * mac * 1e9 / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK[dname]) if mac else None}
+                           "whole_step_frac_of_peak": (2 * k * 2 * mac * 1e9 / (ms_step * 1e-3) / 1e12 / PEAK[dname]) if mac else None,
+                           "launches_per_step": eng.stats()[0]}
 
     if rank == 0 and not a.no_roofline and S == 1:
         # ---- time to a converged basis under the reference's own stop rule (utils.py:803-808: allclose(V_prev, V, atol=1e-3) and
         # i > min_iter=10, at most 100 iterations), host loop with one 8-byte read-back per iteration; not part of `value`
+        x1 = xs[0:1] if xs is not None and xs.shape[0] >= 1 else torch.randn(1, *shape).to(dev)
         torch.cuda.synchronize(dev); tc = time.perf_counter()
         if a.workload == "ddpm256":
-            net.local_encoder_pullback_xt(x=xs[0:1], t=t, op=tap[0], block_idx=tap[1], pca_rank=k, V0=V0)
+            net.local_encoder_pullback_xt(x=x1, t=t, op=tap[0], block_idx=tap[1], pca_rank=k, V0=V0)
         else:
-            net.local_encoder_pullback_zt(sample=xs[0:1], timestep=t, encoder_hidden_states=ctx, op=tap[0], block_idx=tap[1], pca_rank=k, V0=V0)
+            net.local_encoder_pullback_zt(sample=x1, timestep=t, encoder_hidden_states=ctx, op=tap[0], block_idx=tap[1], pca_rank=k, V0=V0)
         torch.cuda.synchronize(dev)
         res["time_to_converged_basis"] = {"ms": 1e3 * (time.perf_counter() - tc), "iters": net.last_iters, "final_dist": net.last_dist,
+                                          "converged": net.last_iters < 100,
                                           "rule": "reference stop rule: allclose(V_prev, V, atol=1e-3) and i > 10, max_iter 100"}
 
     if rank == 0 and not a.no_cpu_baseline and world == 1:
-        # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference) on the host cores
+        # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference), fp32, same
+        # inputs, all physical cores, 1 warm-up + `cpu_iters` timed power iterations
         from oracle import pullback as opb
         ck = min(a.cpu_k, k) if a.cpu_k else k
-        cores = min(os.cpu_count() or 1, 32)      # torch CPU kernels stop scaling (and oversubscribe) far below 256 threads
+        model, logical, physical = cpu_info()
+        x_cpu = (xs[0:1] if xs is not None and xs.shape[0] >= 1 else torch.randn(1, *shape)).cpu()
+        # thread count: the fastest of a short calibration (one get_h forward each) -- torch's CPU kernels stop scaling well below the
+        # 128 cores of the GPU boxes' hosts, and the baseline should be the CPU path at its best, not at its most oversubscribed
+        cand = sorted({c for c in (16, 32, 64, physical, logical) if 1 <= c <= logical})
+        calib = {}
+        if "DPB_CPU_THREADS" in os.environ:
+            cores = int(os.environ["DPB_CPU_THREADS"])
+        else:
+            with torch.no_grad():
+                for c in cand:
+                    torch.set_num_threads(c)
+                    oracle_get_h(x_cpu)
+                    tq = time.perf_counter(); oracle_get_h(x_cpu); calib[c] = time.perf_counter() - tq
+            cores = min(calib, key=calib.get)
         torch.set_num_threads(cores)
-        x_cpu = xs[0:1].cpu()
+        chunk, variant = (5, "zt") if a.workload != "ddpm256" else (25, "xt")
+
+        def cpu_iteration(Vc):
+            u_c = opb.jvp_step(oracle_get_h, x_cpu, Vc, Vc.shape[0], chunk, variant)
+            w_c = opb.vjp_step(oracle_get_h, x_cpu, u_c)
+            return torch.linalg.svd(w_c, full_matrices=False)[2].reshape(Vc.shape)
+        tw0 = time.perf_counter()
+        cpu_iteration(V0[:1].reshape(1, *shape))                       # warm-up: thread pool, allocator, one direction through every op
+        tw = time.perf_counter() - tw0
         Vc = V0[:ck].reshape(ck, *shape)
-        tc0 = time.perf_counter()
-        u_c = opb.jvp_step(oracle_get_h, x_cpu, Vc, ck, 5 if a.workload != "ddpm256" else 25, "zt" if a.workload != "ddpm256" else "xt")
-        w_c = opb.vjp_step(oracle_get_h, x_cpu, u_c)
-        torch.linalg.svd(w_c, full_matrices=False)
-        tc = time.perf_counter() - tc0
-        res["cpu_baseline"] = {"value": (ck / k) / tc, "unit": "iters/s", "cores": cores, "kind": "port",
-                               "sample": f"1 power iteration (k={ck} of {k} directions; JVP+VJP+SVD, fp32) of the same workload, no warm-up, {tc:.1f}s"
+        times = []
+        for _ in range(max(1, a.cpu_iters)):
+            tc0 = time.perf_counter()
+            Vc = cpu_iteration(Vc)
+            times.append(time.perf_counter() - tc0)
+        tc = sum(times) / len(times)
+        res["cpu_baseline"] = {"value": (ck / k) / tc, "unit": "iters/s", "cores": cores, "kind": "port", "cpu_model": model,
+                               "logical_cpus": logical, "physical_cores": physical,
+                               "thread_calibration_s_per_forward": {str(c): round(v, 3) for c, v in calib.items()},
+                               "sample": f"1 warm-up (1 direction, {tw:.1f}s) + {len(times)} timed power iterations (k={ck} of {k} directions; "
+                                         f"JVP+VJP+SVD, fp32, {cores} threads) of the same workload: " + ", ".join(f"{x:.1f}s" for x in times)
                                          + ("" if ck == k else f", scaled by {ck}/{k}")}
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
 

@@ -382,9 +382,17 @@ class CLIPTextConfig:
     intermediate: int = 3072
     max_position: int = 77
     eps: float = 1e-5
+    act: str = "quick_gelu"                        # MLP activation: "quick_gelu" (CLIP ViT-L/14) | "gelu" (OpenCLIP ViT-H/14)
 
 
 SD15_CLIP = CLIPTextConfig()
+# stabilityai/stable-diffusion-2(-1)-base text_encoder/config.json: OpenCLIP ViT-H/14 text tower without its last layer (diffusers ships 23 of the
+# 24 layers: SD-2.x conditions on the penultimate hidden state), 1024 wide, 16 heads, erf GELU; its output is the 1024-wide context of SD21_BASE
+SD21_CLIP = CLIPTextConfig(hidden=1024, layers=23, heads=16, intermediate=4096, act="gelu")
+
+
+def clip_config_for(model_name: str) -> CLIPTextConfig:
+    return SD21_CLIP if sd_config_for(model_name) is SD21_BASE else SD15_CLIP
 
 
 def clip_param_shapes(cfg: CLIPTextConfig) -> Dict[str, Tuple[int, ...]]:

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace dpb {
 
 enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
@@ -169,6 +171,16 @@ template <int FL> __device__ inline void st16(bf16* p, float v) { p->v = H16<FL>
     else { using T = dpb::f16; __VA_ARGS__; }                                         \
   } while (0)
 inline int dt_chunk(int dtype) { return dtype == DT_F32 ? 4 : 8; }   // elements per 16-byte chunk
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1 (keeps indices into register arrays static where `#pragma unroll`
+// is only a hint: a dynamically indexed accumulator array is demoted to scratch memory)
+template <int I, int N, typename F>
+__device__ inline void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -23,40 +23,55 @@ __global__ __launch_bounds__(256) void geglu_kernel(GegluArgs a, long nrows) {
       long j = row / a.rows_per_sample, l = row - j * a.rows_per_sample;
       prow = (j / a.kps) * a.rows_per_sample + l;
     }
+    // column of a-unit c inside a [..][2F] row, and the distance to its gate: plain layout (a | g halves) or 64-blocks interleaved
+    const int ca = a.il ? ((c >> 6) << 7) + (c & 63) : c, dg_ = a.il ? 64 : a.F;
     const T* hp = (const T*)a.h + prow * 2 * a.F;
     float av[CH], gv[CH], o[CH];
-    Vec<T>::load(hp + c, av);
-    Vec<T>::load(hp + a.F + c, gv);
+    Vec<T>::load(hp + ca, av);
+    Vec<T>::load(hp + ca + dg_, gv);
+    // The primal pass REPLACES (a, g) in h by the two factors every tangent / adjoint pass needs,
+    //   G1 = gelu(g)  (in a's slot)   and   G2 = a * gelu'(g)  (in g's slot),
+    // so that  dy = da*G1 + dg*G2  and  (ga, gg) = gy * (G1, G2)  cost two FMAs per element -- cheap enough to live in GEMM epilogues
+    // (epilogue.h); h is read by nothing else after this kernel.
     if (MODE == MODE_PRIMAL) {
+      float g1[CH], g2[CH];
 #pragma unroll
-      for (int e = 0; e < CH; ++e) o[e] = av[e] * gelu_(gv[e]);
+      for (int e = 0; e < CH; ++e) {
+        const float er = erff(gv[e] * 0.70710678118654752f);
+        g1[e] = 0.5f * gv[e] * (1.f + er);
+        g2[e] = av[e] * (0.5f * (1.f + er) + gv[e] * 0.39894228040143268f * __expf(-0.5f * gv[e] * gv[e]));
+        o[e] = av[e] * g1[e];
+      }
       Vec<T>::store((T*)a.y + row * a.F + c, o);
+      T* hw = (T*)a.h + prow * 2 * a.F;
+      Vec<T>::store(hw + ca, g1);
+      Vec<T>::store(hw + ca + dg_, g2);
     } else if (MODE == MODE_TANGENT) {
       const T* dp = (const T*)a.d + row * 2 * a.F;
       float da[CH], dg[CH];
-      Vec<T>::load(dp + c, da);
-      Vec<T>::load(dp + a.F + c, dg);
+      Vec<T>::load(dp + ca, da);
+      Vec<T>::load(dp + ca + dg_, dg);
 #pragma unroll
-      for (int e = 0; e < CH; ++e) o[e] = da[e] * gelu_(gv[e]) + av[e] * dgelu_(gv[e]) * dg[e];
+      for (int e = 0; e < CH; ++e) o[e] = da[e] * av[e] + dg[e] * gv[e];          // av = G1, gv = G2
       Vec<T>::store((T*)a.y + row * a.F + c, o);
     } else {
       float gy[CH], o2[CH];
       Vec<T>::load((const T*)a.d + row * a.F + c, gy);
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
-        o[e] = gy[e] * gelu_(gv[e]);
-        o2[e] = gy[e] * av[e] * dgelu_(gv[e]);
+        o[e] = gy[e] * av[e];
+        o2[e] = gy[e] * gv[e];
       }
       T* yp = (T*)a.y + row * 2 * a.F;
       if (a.accumulate) {
         float t1[CH], t2[CH];
-        Vec<T>::load(yp + c, t1);
-        Vec<T>::load(yp + a.F + c, t2);
+        Vec<T>::load(yp + ca, t1);
+        Vec<T>::load(yp + ca + dg_, t2);
 #pragma unroll
         for (int e = 0; e < CH; ++e) { o[e] += t1[e]; o2[e] += t2[e]; }
       }
-      Vec<T>::store(yp + c, o);
-      Vec<T>::store(yp + a.F + c, o2);
+      Vec<T>::store(yp + ca, o);
+      Vec<T>::store(yp + ca + dg_, o2);
     }
   }
 }
@@ -64,6 +79,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(GegluArgs a, long nrows) {
 template <typename T>
 static int geglu_t(int mode, const GegluArgs& a, hipStream_t st) {
   if (a.F % TT<T>::CH) { set_error("geglu: F=%d not chunk aligned", a.F); return -1; }
+  if (a.il && (a.il != 64 || a.F % 64)) { set_error("geglu: interleave %d with F=%d unsupported (blocks of 64)", a.il, a.F); return -1; }
   long nrows = (long)(mode == MODE_PRIMAL ? a.Bp : a.NT) * a.rows_per_sample;
   unsigned g = grid_for(nrows * (a.F / TT<T>::CH));
   if (mode == MODE_PRIMAL) hipLaunchKernelGGL((geglu_kernel<T, MODE_PRIMAL>), dim3(g), dim3(256), 0, st, a, nrows);
@@ -76,7 +92,7 @@ int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st) {
   return DPB_DISPATCH_T(dtype, T, geglu_t<T>(mode, a, st));
 }
 
-template <typename T, int OP>   // 0: silu  1: y = x  2: y += x  3: quick_gelu
+template <typename T, int OP>   // 0: silu  1: y = x  2: y += x  3: quick_gelu  4: exact (erf) gelu
 __global__ __launch_bounds__(256) void unary_kernel(const T* x, T* y, long nchunks) {
   constexpr int CH = TT<T>::CH;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
@@ -88,6 +104,9 @@ __global__ __launch_bounds__(256) void unary_kernel(const T* x, T* y, long nchun
     } else if (OP == 3) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+    } else if (OP == 4) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] = gelu_(v[e]);
     } else if (OP == 2) {
       float o[CH];
       Vec<T>::load(y + i * CH, o);
@@ -106,6 +125,7 @@ static int unary_t(int op, const void* x, void* y, long n, hipStream_t st) {
   if (op == 0) hipLaunchKernelGGL((unary_kernel<T, 0>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   else if (op == 1) hipLaunchKernelGGL((unary_kernel<T, 1>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   else if (op == 3) hipLaunchKernelGGL((unary_kernel<T, 3>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
+  else if (op == 4) hipLaunchKernelGGL((unary_kernel<T, 4>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   else hipLaunchKernelGGL((unary_kernel<T, 2>), dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, nc);
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -115,6 +135,9 @@ int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st) {
 }
 int launch_quick_gelu(int dtype, const void* x, void* y, long n, hipStream_t st) {
   return DPB_DISPATCH_T(dtype, T, unary_t<T>(3, x, y, n, st));
+}
+int launch_gelu(int dtype, const void* x, void* y, long n, hipStream_t st) {
+  return DPB_DISPATCH_T(dtype, T, unary_t<T>(4, x, y, n, st));
 }
 
 // token + position embedding lookup of the text encoder, written in the engine's fp32 [b][c][t] boundary layout

@@ -57,6 +57,8 @@ struct Op {
   bool is_const = true;
   int attn = -1;             // index into plans
   size_t pstats = 0, tstats = 0;   // GroupNorm stat slots (offsets)
+  int geglu_next = -1;       // CONV (FF-in): the GEGLU op that is the only consumer of its output (interleaved layout) -> fused tangent epilogue
+  int geglu_prev = -1;       // CONV (FF-out): the GEGLU op that produces its input                                   -> fused adjoint epilogue
 };
 
 }  // namespace dpb
@@ -81,6 +83,7 @@ struct dpb_engine {
   size_t temb_host_stage = 0;
   int cur_batch = 0;
   std::vector<char> ginit;
+  std::vector<char> skip;           // ops whose work a fused epilogue of another op has done in the current pass
   long n_launch = 0;
   double flops = 0, gbytes = 0;
   // optional per-launch timing of the GEMM kernel (bench.py roofline leg); off in the timed region
@@ -103,11 +106,15 @@ int fail(const char* fmt, ...) {
   return -1;
 }
 
-int gemm(dpb_engine* e, GemmArgs a) {
-  e->n_launch++;
+void gemm_prep(dpb_engine* e, GemmArgs& a) {
   a.slab = (float*)(e->ws + e->slab);
   a.zeros = e->ws + e->zeros;
   a.slab_bytes = e->slab_bytes;
+}
+
+int gemm(dpb_engine* e, GemmArgs a) {
+  e->n_launch++;
+  gemm_prep(e, a);
   const double kk = (double)a.K + (a.A2 ? a.K2 : 0);
   e->flops += 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
@@ -166,6 +173,17 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
     g.R = mode == 0 ? e->P(d.res) : e->T(d.res);
     g.ldr = e->bufs[d.res].C;
   }
+  if (mode == 1 && op.geglu_next >= 0) {   // FF-in tangent: GEGLU's tangent in the epilogue, dh [rows][2F] is never written
+    const dpb_op_desc& gd = e->ops[op.geglu_next].d;
+    GemmArgs f = g;
+    f.epi = EPI_GEGLU_TAN; f.hprim = e->P(d.out); f.epi_kps = n / e->cur_batch; f.rows_per_sample = bo.rows;
+    f.C = e->T(gd.out); f.ldc = e->bufs[gd.out].C;
+    gemm_prep(e, f);
+    if (gemm_epi_supported(e->dtype, f)) {
+      e->skip[op.geglu_next] = 1;
+      return gemm(e, f);
+    }
+  }
   return gemm(e, g);
 }
 
@@ -186,6 +204,19 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
     g.ldb = g.K;
     g.ldc = bi.C;
     const int gather = d.ip[9];
+    if (gather == GATHER_NONE && op.geglu_prev >= 0) {   // FF-out adjoint: GEGLU's adjoint in the epilogue, gy [rows][F] is never written
+      const dpb_op_desc& gd = e->ops[op.geglu_prev].d;
+      GemmArgs f = g;
+      f.M = n * bi.rows;
+      f.epi = EPI_GEGLU_ADJ; f.hprim = e->P(gd.in0); f.epi_kps = n / e->cur_batch; f.rows_per_sample = bi.rows;
+      f.C = e->G(gd.in0); f.ldc = e->bufs[gd.in0].C; f.accumulate = e->ginit[gd.in0];
+      gemm_prep(e, f);
+      if (gemm_epi_supported(e->dtype, f)) {
+        if (int r = gemm(e, f)) return r;
+        e->ginit[gd.in0] = 1;               // G(d.in0) stays unwritten: the GEGLU op sees ginit == 0 and is skipped
+        goto residual;
+      }
+    }
     if (gather == GATHER_NONE) {
       g.M = n * bi.rows;
       g.C = e->G(d.in0);
@@ -209,6 +240,7 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
     }
     e->ginit[d.in0] = 1;
   }
+residual:
   if (d.res >= 0 && !e->bufs[d.res].is_const) {
     Buf& br = e->bufs[d.res];
     if (!e->ginit[d.res] && br.rows == bo.rows && br.C == bo.C && br.kind == bo.kind) {
@@ -290,7 +322,7 @@ int geglu_run(dpb_engine* e, const Op& op, int mode, int n) {
   const Buf& bi = e->bufs[d.in0];
   GegluArgs a;
   a.h = e->P(d.in0);
-  a.rows_per_sample = bi.rows; a.F = bi.C / 2;
+  a.rows_per_sample = bi.rows; a.F = bi.C / 2; a.il = d.ip[1];
   a.Bp = e->cur_batch;
   if (mode == MODE_PRIMAL) {
     a.Bp = n;
@@ -558,6 +590,8 @@ int run_op(dpb_engine* e, const Op& op, int mode, int n) {
       if (mode != MODE_PRIMAL) return fail("SILU / quick-GELU ops are primal only (time-embedding path, text encoder)");
       const Buf& b = e->bufs[op.d.in0];
       e->n_launch++;
+      if (op.d.ip[0] == 2)
+        return launch_gelu(e->dtype, e->P(op.d.in0), e->P(op.d.out), (long)(b.kind == DPB_BUF_SHARED ? 1 : n) * b.rows * b.C, e->stream);
       if (op.d.ip[0] == 1)
         return launch_quick_gelu(e->dtype, e->P(op.d.in0), e->P(op.d.out), (long)(b.kind == DPB_BUF_SHARED ? 1 : n) * b.rows * b.C, e->stream);
       return launch_silu(e->dtype, e->P(op.d.in0), e->P(op.d.out), (long)(b.kind == DPB_BUF_SHARED ? 1 : n) * b.rows * b.C, e->stream);
@@ -650,6 +684,29 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
     if (e->producer[d.out] >= 0) return bad("buffer written twice (tape must be SSA)", i);
     e->producer[d.out] = i;
     e->ops.push_back(op);
+  }
+  // ---------------- GEGLU fusion pairs: FF-in conv -> GEGLU (interleaved layout, sole consumer) -> FF-out conv (sole consumer)
+  {
+    std::vector<int> uses(nb, 0), user(nb, -1);
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+      const dpb_op_desc& d = e->ops[i].d;
+      for (int b : {d.in0, d.in1, d.in2, d.res}) if (b >= 0 && b < nb) { uses[b]++; user[b] = (int)i; }
+    }
+    for (size_t j = 0; j < e->ops.size(); ++j) {
+      const dpb_op_desc& d = e->ops[j].d;
+      if (d.kind != DPB_OP_GEGLU || d.ip[1] != 64 || e->ops[j].is_const || getenv("DPB_NO_GEGLU_FUSE")) continue;   // (env: A/B tuning switch)
+      const int pi = e->producer[d.in0];
+      if (pi >= 0 && uses[d.in0] == 1) {
+        const dpb_op_desc& pd = e->ops[pi].d;
+        if (pd.kind == DPB_OP_CONV && pd.ip[9] == DPB_GATHER_NONE && pd.res < 0 && e->bufs[d.in0].kind == DPB_BUF_ACT) e->ops[pi].geglu_next = (int)j;
+      }
+      if (uses[d.out] == 1) {
+        const int ci = user[d.out];
+        const dpb_op_desc& cd = e->ops[ci].d;
+        if (cd.kind == DPB_OP_CONV && cd.ip[9] == DPB_GATHER_NONE && cd.in0 == d.out) e->ops[ci].geglu_prev = (int)j;
+      }
+    }
+    e->skip.assign(e->ops.size(), 0);
   }
   // ---------------- memory plan
   size_t off = 0;
@@ -800,8 +857,9 @@ int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
   if (int r = launch_nchw_to_nhwc(e->dtype, V, e->T(e->x_buf), nt, e->x_channels, bx.rows, bx.C, e->stream)) return r;
   if (e->tstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
   const int last = e->producer[tap];
+  std::fill(e->skip.begin(), e->skip.end(), 0);
   for (int i = 0; i <= last; ++i) {
-    if (e->ops[i].is_const) continue;
+    if (e->ops[i].is_const || e->skip[i]) continue;
     if (int r = run_op(e, e->ops[i], MODE_TANGENT, nt)) return r;
   }
   const Buf& bt = e->bufs[tap];
@@ -882,7 +940,7 @@ int dpb_lincomb(const float* x, const float* y, const float* z, float* out, int6
 
 int dpb_engine_profile(dpb_engine* e, int enable) {
   if (!e) return fail("null engine");
-  for (auto& p : e->prof) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& p : e->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   e->prof.clear();
   e->profiling = enable != 0;
   return 0;
@@ -897,7 +955,7 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* path) {
   int i = 0;
   for (auto& p : e->prof) {
     float ms = 0;
-    hipEventElapsedTime(&ms, p.a, p.b);
+    (void)hipEventElapsedTime(&ms, p.a, p.b);
     fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.2f\n", i++, p.big, p.gather, p.M, p.N, p.K, p.Z, ms * 1e3, ms > 0 ? p.flops / (ms * 1e-3) / 1e12 : 0.0);
   }
   fclose(f);

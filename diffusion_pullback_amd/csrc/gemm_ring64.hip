@@ -15,7 +15,7 @@
 // groups of gfx950 ({0-3,12-15,20-27}, ...) the 16 lanes of a group then cover 16 distinct 16-byte bank groups.
 // The swizzle is applied on the SOURCE side (a lane octet permutes the chunks of ONE global line, so requests stay
 // whole lines).  Padding rows / taps / K tails read a 16-byte zero page, so the vmcnt arithmetic stays static.
-#include "kernels.h"
+#include "epilogue.h"
 
 #ifndef DPB_ABLATE
 #define DPB_ABLATE 0   // micro-benchmark builds only (tools/gpu_gemm_ablate.py): 1 no MFMA, 2 no DMA refills, 4 no LDS fragment reads,
@@ -37,11 +37,19 @@ __device__ inline bf16x8 lds_read_frag(unsigned addr) {
 // threaded through it as read-write operands
 template <int N, int NA, int NB>
 __device__ inline void wait_frags(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
-  static_assert(NA <= 4 && NB == 2, "fragment counts of the supported wave tiles");
-  if constexpr (NA == 2) {
+  static_assert((NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2), "fragment counts of the supported wave tiles");
+  if constexpr (NA == 2 && NB == 2) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
-  } else {
+  } else if constexpr (NA == 2 && NB == 1) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]) : "n"(N));
+  } else if constexpr (NA == 4 && NB == 2) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  } else if constexpr (NA == 4 && NB == 1) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]) : "n"(N));
+  } else if constexpr (NA == 5 && NB == 2) {
+    asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]) : "n"(N));
   }
 }
 
@@ -263,80 +271,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     return;
   }
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
-  constexpr int CPR = WN / 8, ITEMS = 32 * CPR / 64;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  static_for<0, TM>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item / CPR, c8 = item % CPR;
-      const int m = m0 + wy * WM + i * 32 + row;
-      const int n = n0 + wx * WN + c8 * 8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
-      Vec<float>::load(stage + row * SLD + c8 * 8, v);
-      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
-      if constexpr ((DPB_ABLATE & 8) != 0) {
-        if (v[0] == 123.456f) reinterpret_cast<float*>(p.C)[0] = v[1];
-        continue;
-      }
-      if (p.splitk > 1) {                           // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
-        float* sp = p.slab + ((long)ksplit * gridDim.y + zb) * (long)p.M * p.N + (long)m * p.N + n;
-        if (n + 8 <= p.N && !(p.N & 3)) {
-          Vec<float>::store(sp, v);
-          Vec<float>::store(sp + 4, v + 4);
-        } else {
-          for (int e = 0; e < 8 && n + e < p.N; ++e) sp[e] = v[e];
-        }
-        continue;
-      }
-      int smp = 0;
-      if (p.rowbias) smp = (m / p.rows_per_sample) / p.rowbias_div;
-      bf16* cp = C + (long)m * p.ldc + n;
-      if (p.vec_ok && n + 8 <= p.N) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-        float b8[8];
-        if (p.bias) {
-          Vec<float>::load(p.bias + n, b8);
-          Vec<float>::load(p.bias + n + 4, b8 + 4);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        if (p.rowbias) {
-          H16<FL>::load8((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        if (R) {
-          H16<FL>::load8(R + (long)m * p.ldr + n, b8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        if (p.accumulate) {
-          H16<FL>::load8(cp, b8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        H16<FL>::store8(cp, v);
-      } else {
-        for (int e = 0; e < 8 && n + e < p.N; ++e) {
-          float x = p.alpha * v[e];
-          if (p.bias) x += p.bias[n + e];
-          if (p.rowbias) x += ld16<FL>((const bf16*)p.rowbias + (long)smp * p.N + n + e);
-          if (R) x += ld16<FL>(R + (long)m * p.ldr + n + e);
-          if (p.accumulate) x += ld16<FL>(cp + e);
-          st16<FL>(cp + e, x);
-        }
-      }
+    if constexpr ((DPB_ABLATE & 8) != 0) {
+      if (stage[lane] == 123.456f) reinterpret_cast<float*>(p.C)[0] = stage[lane + 1];
+    } else {
+      epilogue_slab<FL, WN, SLD>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb);
     }
     __syncthreads();
-  }
+  });
 }
 
 template <int BM, int BN, int S, int WAVES, int FL>
@@ -355,12 +303,16 @@ static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),
-// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB)
+// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB),
+// 520 = 320x128 S2 (112 KiB; 160x64 wave tiles): the M = 64 k rows of the 8x8-level layers at k = 5 in ONE tile -- no padded rows
+// (3 x 128 covers 320 with 17 % waste) and the weight panel is streamed once instead of three times; 521 = 320x64 S3 (144 KiB)
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   const int Z = a.Z1 * a.Z2;
   auto tiles = [&](int bm, int bn) { return dim3(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn), Z, sk); };
-  if (tile == 513) launch_ring64_t<256, 128, 3>(a, tiles(256, 128), st);
+  if (tile == 520) launch_ring64_t<320, 128, 2>(a, tiles(320, 128), st);
+  else if (tile == 521) launch_ring64_t<320, 64, 3>(a, tiles(320, 64), st);
+  else if (tile == 513) launch_ring64_t<256, 128, 3>(a, tiles(256, 128), st);
   else if (tile == 516) launch_ring64_t<256, 128, 3, 8>(a, tiles(256, 128), st);
   else if (tile == 517) launch_ring64_t<256, 128, 2, 8>(a, tiles(256, 128), st);
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);

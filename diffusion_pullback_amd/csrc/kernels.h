@@ -10,6 +10,7 @@ namespace dpb {
 // C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k]  (+bias[n]) (+rowbias[sample(m)][n]) (+R[z][m][n]) (+C if accumulate)
 // A: plain rows (lda) or gathered NHWC pixels (conv).  B is always [N][K], K contiguous.
 enum { GATHER_NONE = 0, GATHER_CONV = 1, GATHER_CONVT = 2, GATHER_UPCONV = 3 };
+enum { EPI_PLAIN = 0, EPI_GEGLU_TAN = 1, EPI_GEGLU_ADJ = 2 };   // fused epilogues of the ring GEMMs (epilogue.h)
 struct GemmArgs {
   const void* A = nullptr; const void* B = nullptr; void* C = nullptr; const void* R = nullptr;
   const float* bias = nullptr;
@@ -34,6 +35,10 @@ struct GemmArgs {
   float* slab = nullptr; size_t slab_bytes = 0;
   const void* zeros = nullptr;        // >= 16 zero bytes in device memory (DMA kernel reads it for padding / out-of-range rows)
   int splitk = 1, vec_ok = 0;
+  // fused GEGLU epilogues (ring kernels with 128-column tiles, no split-K): primal FF-in output [prows][2F], columns interleaved in
+  // blocks of 64 (a | g); tangent row m belongs to primal sample (m / rows_per_sample) / epi_kps
+  int epi = EPI_PLAIN, epi_kps = 1;
+  const void* hprim = nullptr;
   int fl = 0;                         // 16-bit flavour of the specialised kernels: 0 bf16, 1 f16 (filled in by launch_gemm)
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
@@ -46,6 +51,7 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st);   // BK = 6
 int conv_halo_supported(const GemmArgs& a);                        // 3x3 stride-1 convolution in halo-tile form (gemm_halo.hip)
 int launch_conv_halo(const GemmArgs& a, hipStream_t st);
 int gemm_uses_halo(int dtype, const GemmArgs& a);
+int gemm_epi_supported(int dtype, const GemmArgs& a);   // can this launch take GemmArgs::epi != EPI_PLAIN?
 int gemm_uses_dma(int dtype, const GemmArgs& a);   // 0 = register-staged kernel, else the tile code for launch_gemm_dma
 void gemm_debug_dma_auto(int on);
 void gemm_debug_order(int o);   // -1 heuristic, 0 A-major, 1 B-major
@@ -123,10 +129,12 @@ struct GegluArgs {
   void* y = nullptr;           // primal y [.. F] / tangent dy [.. F] / cotangent gh [.. 2F]
   int rows_per_sample = 0, Bp = 1, NT = 0, kps = 1, F = 0;
   int accumulate = 0;
+  int il = 0;                  // 0: h = [a | g] halves; 64: a / g interleaved in blocks of 64 columns (FF-in weight rows repacked, tape.py)
 };
 int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st);
 int launch_silu(int dtype, const void* x, void* y, long n, hipStream_t st);
-int launch_quick_gelu(int dtype, const void* x, void* y, long n, hipStream_t st);   // x * sigmoid(1.702 x) (CLIP text encoder MLP)
+int launch_quick_gelu(int dtype, const void* x, void* y, long n, hipStream_t st);   // x * sigmoid(1.702 x) (CLIP ViT-L text encoder MLP)
+int launch_gelu(int dtype, const void* x, void* y, long n, hipStream_t st);         // exact erf GELU (OpenCLIP-H text encoder MLP of SD-2.x)
 // out[b][c][t] = tok[ids[b][t]][c] + pos[t][c]  (fp32, the engine's NCHW boundary layout with H*W = L tokens); tables in `dtype`
 int launch_embed_tokens(int dtype, const int* ids, const void* tok, const void* pos, float* out, int batch, int L, int C, int vocab, hipStream_t st);
 int launch_axpy(int dtype, const void* x, void* y, long n, int accumulate, hipStream_t st);   // y (+)= x

@@ -24,10 +24,10 @@ def shard_indices(n_samples: int, rank: int, world: int) -> List[int]:
 def gather_bases(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n_samples: int, group=None):
     """local: {sample_idx: (u [N_h,k], s [k], vT [k,N_in])} for this rank's samples.
     Returns the full {idx: (u, s, vT)} on every rank with ONE all_gather of a packed buffer."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
+    if not dist.is_initialized():          # plain single-process use: nothing to exchange
         return dict(local)
+    world = dist.get_world_size(group)      # an initialised group runs the collective even at world_size 1 (RCCL path testable on 1 GPU)
+    rank = dist.get_rank(group)
     any_item = next(iter(local.values())) if local else None
     meta = torch.zeros(3, dtype=torch.int64)
     if any_item is not None:

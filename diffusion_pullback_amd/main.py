@@ -154,7 +154,7 @@ def build_prompt_encoder(args):
     if args.text_encoder == "none" or not args.is_stable_diffusion or args.net_scale != "full":
         return None
     from .text_encoder import ClipTextEncoder
-    cfg = cf.SD15_CLIP
+    cfg = cf.clip_config_for(args.model_name)
     if args.tokenizer_dir:
         from transformers import CLIPTokenizer
         tk = CLIPTokenizer.from_pretrained(args.tokenizer_dir)

@@ -52,14 +52,22 @@ class Tape:
         self.keep.append(t)
         return t.data_ptr()
 
-    def _conv_w(self, name, cin_p: int, cout_p: int, need_adj: bool):
+    def _conv_w(self, name, cin_p: int, cout_p: int, need_adj: bool, interleave: int = 0):
         """``name`` may be a tuple of parameter names: their weights (and biases) are concatenated along Cout,
-        which fuses projections that read the same input (q/k/v) into one GEMM."""
-        key = f"{name}|{cin_p}|{cout_p}|{need_adj}"
+        which fuses projections that read the same input (q/k/v) into one GEMM.  ``interleave`` = 64 permutes the output rows of a
+        GEGLU projection from [a | g] halves to alternating 64-row blocks a0 g0 a1 g1 ..., so one 128-column GEMM tile holds a hidden
+        unit's value AND gate (fused GEGLU epilogues, csrc/epilogue.h)."""
+        key = f"{name}|{cin_p}|{cout_p}|{need_adj}|{interleave}"
         if key in self._wcache:
             return self._wcache[key]
         names = name if isinstance(name, tuple) else (name,)
         w = torch.cat([self.p[n + ".weight"].float() for n in names], dim=0)
+        perm = None
+        if interleave:
+            f = w.shape[0] // 2
+            blk = torch.arange(f).reshape(f // interleave, interleave)
+            perm = torch.stack([blk, blk + f], dim=1).reshape(-1)              # a-block b, g-block b, a-block b+1, ...
+            w = w[perm]
         if w.dim() == 2:
             w = w[:, :, None, None]
         cout, cin, kh, kw = w.shape
@@ -75,6 +83,8 @@ class Tape:
         b = None
         if any(x is not None for x in bs):
             b = torch.cat([x.float() if x is not None else torch.zeros(self.p[n + ".weight"].shape[0]) for x, n in zip(bs, names)])
+            if perm is not None:
+                b = b[perm]
         pb = self._dev(b.float(), torch.float32) if b is not None else 0
         self._wcache[key] = (pf, pa, pb)
         return pf, pa, pb
@@ -86,7 +96,8 @@ class Tape:
         self.ops.append(d)
 
     def conv(self, name: str, x: int, hw: Tuple[int, int], cout: int, ks: int = 3, stride: int = 1, pad: int = 1,
-             upsample: bool = False, res: int = -1, rowbias: int = -1, need_adj: bool = True, kind: int = L.BUF_ACT) -> int:
+             upsample: bool = False, res: int = -1, rowbias: int = -1, need_adj: bool = True, kind: int = L.BUF_ACT,
+             interleave: int = 0) -> int:
         """3x3 / strided / upsampling convolution, 1x1 convolution or Linear (ks=1)."""
         rows, cin_p, _ = self.buffers[x]
         h, w = hw
@@ -100,7 +111,7 @@ class Tape:
             gather = L.GATHER_CONV
         cout_p = _r8(cout)
         out = self.buf(ho * wo if ks != 1 else rows, cout_p, kind, cout if cout != cout_p else 0)
-        pf, pa, pb = self._conv_w(name, cin_p, cout_p, need_adj)
+        pf, pa, pb = self._conv_w(name, cin_p, cout_p, need_adj, interleave)
         self._op(kind=L.OP_CONV, in0=x, out=out, res=res, rowbias=rowbias,
                  ip=[h, w, cin_p, ho, wo, cout, ks, stride, pad, gather, 0, 0], w=[pf, pa, pb, 0])
         return out
@@ -127,10 +138,10 @@ class Tape:
         self._op(kind=L.OP_ATTENTION, in0=q, in1=k, in2=v, out=out, ip=[heads, offsets[0], offsets[1], offsets[2], int(causal)] + [0] * 7)
         return out
 
-    def geglu(self, x: int) -> int:
+    def geglu(self, x: int, interleave: int = 0) -> int:
         rows, c, _ = self.buffers[x]
         out = self.buf(rows, c // 2)
-        self._op(kind=L.OP_GEGLU, in0=x, out=out, ip=[c // 2] + [0] * 11)
+        self._op(kind=L.OP_GEGLU, in0=x, out=out, ip=[c // 2, interleave] + [0] * 10)
         return out
 
     def silu(self, x: int) -> int:
@@ -144,6 +155,13 @@ class Tape:
         rows, c, kind = self.buffers[x]
         out = self.buf(rows, c, kind)
         self._op(kind=L.OP_SILU, in0=x, out=out, ip=[1] + [0] * 11)
+        return out
+
+    def gelu(self, x: int) -> int:
+        """exact (erf) GELU (OpenCLIP-H MLP activation); primal only."""
+        rows, c, kind = self.buffers[x]
+        out = self.buf(rows, c, kind)
+        self._op(kind=L.OP_SILU, in0=x, out=out, ip=[2] + [0] * 11)
         return out
 
     def concat(self, a: int, b: int) -> int:
@@ -269,7 +287,8 @@ def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None)
         kv = t.conv((tb + ".attn2.to_k", tb + ".attn2.to_v"), t.ctx, (1, 1), 2 * c, ks=1, need_adj=False)     # fused k/v of the context
         h = t.conv(tb + ".attn2.to_out.0", t.attention(q, kv, kv, heads, c, (0, 0, c)), (r, r), c, ks=1, res=h)
         z = t.layernorm(tb + ".norm3", h)
-        f = t.geglu(t.conv(tb + ".ff.net.0.proj", z, (r, r), 8 * c, ks=1))
+        il = 64 if (4 * c) % 64 == 0 else 0                                     # a / g interleaved in 64-column blocks: GEGLU fuses into GEMM epilogues
+        f = t.geglu(t.conv(tb + ".ff.net.0.proj", z, (r, r), 8 * c, ks=1, interleave=il), il)
         h = t.conv(tb + ".ff.net.2", f, (r, r), c, ks=1, res=h)
         return t.conv(pre + ".proj_out", h, (r, r), c, ks=1, res=x)
 
@@ -410,7 +429,8 @@ def build_clip_text(cfg, params, dtype, device) -> Tape:
         a = t.attention(qkv, qkv, qkv, cfg.heads, h, (0, h, 2 * h), causal=True)
         x = t.conv(pre + ".self_attn.out_proj", a, (n, 1), h, ks=1, res=x, need_adj=False)
         z = t.layernorm(pre + ".layer_norm2", x, cfg.eps)
-        f = t.quick_gelu(t.conv(pre + ".mlp.fc1", z, (n, 1), cfg.intermediate, ks=1, need_adj=False))
+        act = t.quick_gelu if cfg.act == "quick_gelu" else t.gelu
+        f = act(t.conv(pre + ".mlp.fc1", z, (n, 1), cfg.intermediate, ks=1, need_adj=False))
         x = t.conv(pre + ".mlp.fc2", f, (n, 1), h, ks=1, res=x, need_adj=False)
     o = t.layernorm("text_model.final_layer_norm", x, cfg.eps)
     t.tap("last_hidden_state", o, h, n, 1)

@@ -36,7 +36,7 @@ enum {
   DPB_OP_LAYERNORM = 3, /* LayerNorm over channels                                                     */
   DPB_OP_ATTENTION = 4, /* multi-head softmax(q k^T d^-1/2) v ; in0=q in1=k in2=v                      */
   DPB_OP_GEGLU = 5,     /* [rows][2F] -> [rows][F] : a * gelu_erf(g)                                   */
-  DPB_OP_SILU = 6,      /* elementwise x*sigmoid(x); ip[0] = 1: quick-GELU x*sigmoid(1.702x) (primal only) */
+  DPB_OP_SILU = 6,      /* elementwise x*sigmoid(x); ip[0] = 1: quick-GELU x*sigmoid(1.702x), 2: erf GELU (primal only) */
   DPB_OP_CONCAT = 7     /* channel concat of in0, in1                                                  */
 };
 enum { DPB_GATHER_NONE = 0, DPB_GATHER_CONV = 1, DPB_GATHER_UPCONV = 3 };
@@ -57,7 +57,7 @@ typedef struct dpb_op_desc {
   int32_t res;               /* CONV: buffer added to the output (residual / shortcut), -1 = none */
   int32_t rowbias;           /* CONV: DPB_BUF_SHARED buffer [1][Cout] added to every row (temb projection), -1 */
   int32_t ip[12];            /* CONV: H W Cin Ho Wo Cout KS stride pad gather ; GROUPNORM: G silu ;
-                                ATTENTION: heads oq ok ov causal ; GEGLU: F                                                  */
+                                ATTENTION: heads oq ok ov causal ; GEGLU: F interleave(0|64)                                               */
   float fp[4];               /* GROUPNORM/LAYERNORM: eps */
   const void* w[4];          /* CONV: w[0]=W [Cout][KS*KS*Cin] (engine dtype), w[1]=W^T [Cin][KS*KS*Cout]
                                 (engine dtype, for the adjoint; may be NULL for ops never differentiated),

@@ -13,7 +13,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from diffusion_pullback_amd.configs import SD15_CLIP, CLIPTextConfig, Params  # noqa: F401
+from diffusion_pullback_amd.configs import SD15_CLIP, SD21_CLIP, CLIPTextConfig, Params  # noqa: F401
 from diffusion_pullback_amd.configs import clip_init_params as init_params  # noqa: F401
 from diffusion_pullback_amd.configs import clip_param_shapes as param_shapes  # noqa: F401
 
@@ -40,6 +40,6 @@ def encode(p: Params, cfg: CLIPTextConfig, ids: torch.Tensor) -> torch.Tensor:
         x = x + F.linear(a, p[pre + ".self_attn.out_proj.weight"], p[pre + ".self_attn.out_proj.bias"])
         z = F.layer_norm(x, (h,), p[pre + ".layer_norm2.weight"], p[pre + ".layer_norm2.bias"], cfg.eps)
         f = F.linear(z, p[pre + ".mlp.fc1.weight"], p[pre + ".mlp.fc1.bias"])
-        f = f * torch.sigmoid(1.702 * f)
+        f = f * torch.sigmoid(1.702 * f) if cfg.act == "quick_gelu" else F.gelu(f)
         x = x + F.linear(f, p[pre + ".mlp.fc2.weight"], p[pre + ".mlp.fc2.bias"])
     return F.layer_norm(x, (h,), p["text_model.final_layer_norm.weight"], p["text_model.final_layer_norm.bias"], cfg.eps)

@@ -91,7 +91,7 @@ def _transformer(p, pre, x, ctx, heads, cfg):
     a, g = f.chunk(2, dim=-1)
     h = h + _lin(p, tb + ".ff.net.2", a * F.gelu(g))
     if cfg.use_linear_projection:
-        h = _lin(p, pre + ".proj_out", h).reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+        h = _lin(p, pre + ".proj_out", h).reshape(b, hh, ww, c).permute(0, 3, 1, 2).contiguous()
     else:
         h = _conv(p, pre + ".proj_out", h.reshape(b, hh, ww, c).permute(0, 3, 1, 2), padding=0)
     return h + x

@@ -334,3 +334,33 @@ def test_stop_rule_iteration_count_and_history(case):
     torch.testing.assert_close(torch.tensor(net.last_history), torch.tensor(dists[:n]), rtol=5e-2, atol=2e-4)
     if case == 0:
         assert stop is not None and stop < c["max_iter"] and not c["converged"]    # converges here, while the reference ran to max_iter
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_geglu_epilogues_match_unfused_path(dtype, monkeypatch):
+    """GEGLU's tangent lives in the FF-in GEMM epilogue and its adjoint in the FF-out adjoint epilogue (csrc/epilogue.h, interleaved
+    a / g weight rows): same results as the unfused GEMM -> geglu kernel chain, with fewer launches (64 x 64 latents so that the
+    products are large enough for the 128-column ring kernels that carry the fused epilogues)."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=64, ctx_len=77)
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 4, 64, 64, generator=g); ctx = torch.randn(1, 77, 768, generator=g)
+    V = torch.randn(3, 4 * 64 * 64, generator=g).cuda(); U = torch.randn(3, 640 * 32 * 32, generator=g).cuda()
+    tap = ("mid", 0)
+
+    def run():
+        net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=1, max_rank=3, upto=tap, verbose=False)
+        net.engine.primal(z, 696.2727, ctx, tap)
+        jv = net.engine.jvp(tap, V).clone(); nj = net.engine.stats()[0]
+        ju = net.engine.vjp(tap, U).clone(); nv = net.engine.stats()[0]
+        return jv, ju, nj, nv
+    fused = run()
+    monkeypatch.setenv("DPB_NO_GEGLU_FUSE", "1")
+    plain = run()
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3          # the unfused chain rounds dh / gy to 16 bit once more
+    assert rel(fused[0], plain[0]) < tol and rel(fused[1], plain[1]) < tol, (rel(fused[0], plain[0]), rel(fused[1], plain[1]))
+    print("launches fused", fused[2:], "unfused", plain[2:])
+    assert fused[2] < plain[2] and fused[3] < plain[3], (fused[2:], plain[2:])

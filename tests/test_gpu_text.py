@@ -47,3 +47,21 @@ def test_sd15_clip_text_encoder_full_size_bf16():
     ref = oc.encode({k: v.to(torch.bfloat16).float() for k, v in p.items()}, cfg, ids)
     assert e.shape == (1, 77, 768) and torch.isfinite(e).all()
     assert rel(e, ref) < 3e-2, rel(e, ref)
+
+
+def test_sd21_openclip_text_encoder_shapes_fp16_and_bf16():
+    """SD-2.x prompt encoder: OpenCLIP ViT-H/14 text tower (1024 wide, 16 heads of 64, erf GELU), reduced depth for the CPU oracle;
+    its 1024-wide output is the context width of configs.SD21_BASE."""
+    from diffusion_pullback_amd import configs as cf
+    from diffusion_pullback_amd.text_encoder import ClipTextEncoder
+    from oracle import clip_text as oc
+    assert cf.SD21_CLIP.hidden == cf.SD21_BASE.cross_dim == 1024 and cf.SD21_CLIP.layers == 23 and cf.SD21_CLIP.act == "gelu"
+    assert cf.clip_config_for("stabilityai/stable-diffusion-2-1-base") is cf.SD21_CLIP and cf.clip_config_for("runwayml/stable-diffusion-v1-5") is cf.SD15_CLIP
+    cfg = cf.CLIPTextConfig(vocab_size=1000, hidden=1024, layers=2, heads=16, intermediate=4096, max_position=77, act="gelu")
+    p = cf.clip_init_params(cfg, seed=6)
+    ids = torch.randint(0, cfg.vocab_size, (1, 77), generator=torch.Generator().manual_seed(1))
+    for dtype, tol in ((torch.bfloat16, 3e-2), (torch.float16, 5e-3)):
+        enc = ClipTextEncoder(cfg, p, dtype=dtype, device="cuda:0", max_batch=1)
+        ref = oc.encode({k: v.to(dtype).float() for k, v in p.items()}, cfg, ids.long())
+        y = enc(ids).cpu()
+        assert y.shape == (1, 77, 1024) and rel(y, ref) < tol, (dtype, rel(y, ref))

@@ -1,0 +1,9 @@
+# One GPU-box session: the -m gpu tests, the headline bench line and the rocprofv3 kernel-trace summary of the same command.
+#   gpurun -- 'bash tools/gpu_session.sh TAG [pytest-args...]'      (outputs under gpurun_out/TAG_*)
+TAG=${1:-sess}; shift
+R=$PWD
+python -m pytest tests -m gpu -q -s "$@" > gpurun_out/${TAG}_pytest.log 2>&1; tail -4 gpurun_out/${TAG}_pytest.log
+DPB_PROFILE_CSV=gpurun_out/${TAG}_gemm_launches.csv python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-600 gpurun_out/${TAG}_bench.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -o sd15 -- python $R/bench.py --steps 36 --warmup 12 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+cd $R; python tools/kernel_avgs.py $(ls gpurun_out/${TAG}_stats/*/*kernel_stats.csv gpurun_out/${TAG}_stats/*kernel_stats.csv 2>/dev/null | head -1) 36 30 > gpurun_out/${TAG}_kernel_avgs.txt 2>&1; head -40 gpurun_out/${TAG}_kernel_avgs.txt
