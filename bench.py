@@ -295,7 +295,7 @@ def main():
         x_cpu = (xs[0:1] if xs is not None and xs.shape[0] >= 1 else torch.randn(1, *shape)).cpu()
         # thread count: the fastest of a short calibration (one get_h forward each) -- torch's CPU kernels stop scaling well below the
         # 128 cores of the GPU boxes' hosts, and the baseline should be the CPU path at its best, not at its most oversubscribed
-        cand = sorted({c for c in (16, 32, 64, physical, logical) if 1 <= c <= logical})
+        cand = sorted({c for c in (8, 16, 32, 64, physical) if 1 <= c <= logical})
         calib = {}
         if "DPB_CPU_THREADS" in os.environ:
             cores = int(os.environ["DPB_CPU_THREADS"])
@@ -305,6 +305,8 @@ def main():
                     torch.set_num_threads(c)
                     oracle_get_h(x_cpu)
                     tq = time.perf_counter(); oracle_get_h(x_cpu); calib[c] = time.perf_counter() - tq
+                    if calib[c] > 1.5 * min(calib.values()):          # past the scaling knee: larger counts only oversubscribe
+                        break
             cores = min(calib, key=calib.get)
         torch.set_num_threads(cores)
         chunk, variant = (5, "zt") if a.workload != "ddpm256" else (25, "xt")

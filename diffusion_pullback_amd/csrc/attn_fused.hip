@@ -955,6 +955,8 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   return 0;
 }
 
+// (Running the query-major kernel (gQ) on a side stream next to the key-major kernel (gK, gV) -- they write disjoint column windows -- was
+// measured in round 2: both kernels hold a CU's LDS alone, so they time-slice instead of overlapping: 587 us for the pair vs 585 us back to back.)
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
   dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);

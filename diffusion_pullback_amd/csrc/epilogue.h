@@ -1,7 +1,7 @@
 // Shared epilogue of the LDS-ring GEMM kernels (gemm_dma.hip, gemm_ring64.hip): one 32-row slab of a wave's accumulators has been
 // staged in LDS as fp32 ([wave][32][SLD], written by every wave, then __syncthreads()); this writes it out as 16-byte row segments.
 //
-// Modes (GemmArgs::epi):
+// Modes (GemmArgs::epi, a compile-time parameter of the kernels; the fused ones exist for plain-row A operands only):
 //   EPI_PLAIN      C = alpha*acc (+bias) (+rowbias) (+R) (+C), or a raw fp32 split-K slab
 //   EPI_GEGLU_TAN  tangent of GEGLU fused into the FF-in product: the weight rows are interleaved in blocks of 64 (tape.py), so the
 //                  wave pair (wx = 0, 1) of a 128-column tile holds da | dg of the SAME 64 hidden units; with the primal factors
@@ -14,13 +14,13 @@
 
 namespace dpb {
 
-template <int FL, int WN, int SLD>
-__device__ inline void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0, int n0,
+template <int FL, int WN, int SLD, int EPI>
+__device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0, int n0,
                                      long slab_idx) {
   constexpr int CPR = WN / 8;
   const int wx = wave & 1;
   const float* stage = smem_f + wave * 32 * SLD;
-  if (p.epi == EPI_GEGLU_TAN) {
+  if constexpr (EPI == EPI_GEGLU_TAN) {
     if constexpr (WN == 64) {
       const float* sa = smem_f + (wave & ~1) * 32 * SLD;      // a-half staged by wave wx = 0, g-half by its sibling wx = 1
       const float* sg = sa + 32 * SLD;
@@ -57,7 +57,7 @@ __device__ inline void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, 
     float v[8];
     Vec<float>::load(stage + row * SLD + c8 * 8, v);
     Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
-    if (p.splitk > 1) {                           // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
+    if (EPI == EPI_PLAIN && p.splitk > 1) {       // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
       float* sp = p.slab + slab_idx * (long)p.M * p.N + (long)m * p.N + n;
       if (n + 8 <= p.N && !(p.N & 3)) {
         Vec<float>::store(sp, v);
@@ -67,7 +67,7 @@ __device__ inline void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, 
       }
       continue;
     }
-    if (p.epi == EPI_GEGLU_ADJ) {                 // v = gy of hidden units n..n+7 (n % 8 == 0, N = F % 64 == 0)
+    if constexpr (EPI == EPI_GEGLU_ADJ) {                 // v = gy of hidden units n..n+7 (n % 8 == 0, N = F % 64 == 0)
       const int F2 = 2 * p.N;
       const int ni = ((n >> 6) << 7) + (n & 63);   // interleaved column of a; g sits 64 further
       const int smp = m / p.rows_per_sample, l = m - smp * p.rows_per_sample;

@@ -460,7 +460,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (g_force_tile == 257) return 256;
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
-  if ((g_force_tile >= 512 && g_force_tile <= 517) || g_force_tile == 520 || g_force_tile == 521) return g_force_tile;
+  if (g_force_tile >= 512 && g_force_tile <= 517) return g_force_tile;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
@@ -469,8 +469,6 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (!g_dma_auto || a.K < 256) return 0;
   // BK = 64 ring (gemm_ring64.hip: whole-line DMA + in-wave fragment prefetch, 128x128 tile, 2 stages -> 2 blocks/CU):
   // ahead of the BK = 32 rings by 10-35 % from ~8 stages of K on, with split-K when the tiles leave CUs idle
-  static const int skinny = getenv("DPB_GEMM_SKINNY") ? atoi(getenv("DPB_GEMM_SKINNY")) : 520;    // tuning switch (0: off, 520 | 521)
-  if (skinny && a.K >= 2048 && a.Z1 * a.Z2 == 1 && (a.M == 320 || a.M == 640) && a.epi == EPI_PLAIN) return skinny;   // weight-heavy 8x8-level layers
   if (a.K >= 512 && (t128 >= 200 || a.K >= 2048)) return 515;
   // (3-stage ring = 48 KiB -> 3 blocks/CU measured slightly ahead of 4 stages / 2 blocks and 2 stages / 5 blocks)
   if (t128 >= 400) return 130;                  // chip filled by 128x128 tiles
@@ -490,17 +488,13 @@ int gemm_epi_supported(int dtype, const GemmArgs& a) {
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = tile == 521 ? 64 : (tile == 128 || tile == 130 || tile == 132 || tile == 256 || tile >= 512) ? 128 : 64;
-  const int TMm = (tile == 520 || tile == 521) ? 320 : (tile == 256 || tile == 513 || tile == 516 || tile == 517) ? 256 : T;
+  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256 || tile >= 512) ? 128 : 64;
+  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517) ? 256 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;
   if (g_force_splitk) s = g_force_splitk;
-  else if (tile >= 520) {                       // one resident block per CU: ~one round of blocks, >= 8 stages of 64 each
-    static const int target = getenv("DPB_GEMM_SKINNY_BLOCKS") ? atoi(getenv("DPB_GEMM_SKINNY_BLOCKS")) : 240;     // tuning switch
-    s = std::max<long>(1, target / tiles);
-    s = std::min<long>(s, std::max(1, nk / 16));
-  } else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
+  else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
     if (tiles >= 384) return 1;
     s = std::max<long>(1, (512 + tiles / 2) / tiles);
     s = std::min<long>(s, std::max(1, nk / 16));

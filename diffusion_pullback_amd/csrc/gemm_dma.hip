@@ -27,7 +27,7 @@ __device__ inline bf16x8 lds_read_b128(unsigned addr) {
   return v;
 }
 
-template <int BM, int BN, int S, int GATHER, int FL = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16
+template <int BM, int BN, int S, int GATHER, int FL = 0, int EPI = EPI_PLAIN>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; EPI: epilogue.h
 __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   constexpr int BK = 32, CH = 8;
   constexpr int NIA = BM / 64, NIB = BN / 64;                          // DMA wave-instructions per stage per wave (A, B)
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    epilogue_slab<FL, WN, SLD>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0,
+    epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0,
                                (long)blockIdx.z * gridDim.y + blockIdx.y);
     __syncthreads();
   }
@@ -241,7 +241,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
 template <int BM, int BN, int S, int FL>
 static void launch_dma_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
-    case GATHER_NONE: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL>), grid, dim3(256), 0, st, a); break;
+    case GATHER_NONE:
+      if (a.epi == EPI_GEGLU_TAN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL, EPI_GEGLU_TAN>), grid, dim3(256), 0, st, a);
+      else if (a.epi == EPI_GEGLU_ADJ) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL, EPI_GEGLU_ADJ>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL>), grid, dim3(256), 0, st, a);
+      break;
     case GATHER_CONV: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONV, FL>), grid, dim3(256), 0, st, a); break;
     case GATHER_CONVT: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONVT, FL>), grid, dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_UPCONV, FL>), grid, dim3(256), 0, st, a); break;

@@ -62,7 +62,7 @@ __device__ inline void wait_dma(int stages_in_flight) {   // s_waitcnt vmcnt(sta
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16
+template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0, int EPI = EPI_PLAIN>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; EPI: epilogue.h
 __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   constexpr int BK = 64, CH = 8, KK = BK / 16;
   constexpr int NIA = BM / (8 * WAVES), NIB = BN / (8 * WAVES), U = NIA + NIB;   // DMA wave-instructions (8 rows each) per stage per wave
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     if constexpr ((DPB_ABLATE & 8) != 0) {
       if (stage[lane] == 123.456f) reinterpret_cast<float*>(p.C)[0] = stage[lane + 1];
     } else {
-      epilogue_slab<FL, WN, SLD>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb);
+      epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb);
     }
     __syncthreads();
   });
@@ -290,7 +290,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
 template <int BM, int BN, int S, int WAVES, int FL>
 static void launch_ring64_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
-    case GATHER_NONE: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
+    case GATHER_NONE:
+      if (a.epi == EPI_GEGLU_TAN) hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_TAN>), grid, dim3(WAVES * 64), 0, st, a);
+      else if (a.epi == EPI_GEGLU_ADJ) hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_ADJ>), grid, dim3(WAVES * 64), 0, st, a);
+      else hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a);
+      break;
     case GATHER_CONV: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONV, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
     case GATHER_CONVT: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONVT, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
     default: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_UPCONV, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
@@ -303,16 +307,14 @@ static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),
-// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB),
-// 520 = 320x128 S2 (112 KiB; 160x64 wave tiles): the M = 64 k rows of the 8x8-level layers at k = 5 in ONE tile -- no padded rows
-// (3 x 128 covers 320 with 17 % waste) and the weight panel is streamed once instead of three times; 521 = 320x64 S3 (144 KiB)
+// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB).
+// (320x128 / 320x64 tiles -- the M = 64 k rows of the 8x8-level layers at k = 5 in ONE tile, weight panel streamed once -- were built
+// and measured in round 2: one 4-wave block per CU is latency-bound, 47-52 us against 41 us for 128x128 S2 with split-K 8; removed.)
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   const int Z = a.Z1 * a.Z2;
   auto tiles = [&](int bm, int bn) { return dim3(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn), Z, sk); };
-  if (tile == 520) launch_ring64_t<320, 128, 2>(a, tiles(320, 128), st);
-  else if (tile == 521) launch_ring64_t<320, 64, 3>(a, tiles(320, 64), st);
-  else if (tile == 513) launch_ring64_t<256, 128, 3>(a, tiles(256, 128), st);
+  if (tile == 513) launch_ring64_t<256, 128, 3>(a, tiles(256, 128), st);
   else if (tile == 516) launch_ring64_t<256, 128, 3, 8>(a, tiles(256, 128), st);
   else if (tile == 517) launch_ring64_t<256, 128, 2, 8>(a, tiles(256, 128), st);
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
