@@ -191,6 +191,10 @@ def main():
                 eng.iterate(tap, V0_d[:len(groups[0]) * k].clone(), min(ITERS_PER_SAMPLE, max(1, a.warmup)))
         else:
             run_weak(a.warmup, xs)
+    if dist and a.warmup > 0:                             # untimed: RCCL sets up its channels on the first all_gather of a size class
+        wz = {i: (torch.zeros(n_h, k, device=dev), torch.zeros(k, device=dev), torch.zeros(k, n_in, device=dev))
+              for i in pdist.shard_indices(world * max(1, S), rank, world)}
+        pdist.gather_bases(wz, world * max(1, S))
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -285,6 +289,26 @@ def main():
         res["time_to_converged_basis"] = {"ms": 1e3 * (time.perf_counter() - tc), "iters": net.last_iters, "final_dist": net.last_dist,
                                           "converged": net.last_iters < 100,
                                           "rule": "reference stop rule: allclose(V_prev, V, atol=1e-3) and i > 10, max_iter 100"}
+
+    if rank == 0 and not a.no_roofline and not strong and S == 1 and a.workload == "sd15":
+        # ---- throughput with several x_t samples advanced together (what a multi-sample job such as BASELINE configs[3] runs per GPU): the
+        # weight stream and every launch are shared by the samples.  Reported next to `value` (which stays the one-sample-at-a-time rate).
+        SB = 4
+        try:
+            netb = make_workload(a.workload, dtype, dev, k, SB, tap, a.ctx, not a.flat_spectrum)[0]
+            xb = torch.randn(SB, *shape, generator=torch.Generator().manual_seed(77)).to(dev)
+            cb = ctx.to(dev).expand(SB, -1, -1).contiguous()
+            Vb = V0.to(dev).repeat(SB, 1).contiguous()
+            netb.engine.primal(xb, t, cb, tap); netb.engine.iterate(tap, Vb.clone(), 2)
+            torch.cuda.synchronize(dev); tb = time.perf_counter()
+            for _ in range(2):
+                netb.engine.primal(xb, t, cb, tap); netb.engine.iterate(tap, Vb.clone(), ITERS_PER_SAMPLE)
+            torch.cuda.synchronize(dev)
+            res["batched_throughput"] = {"samples_advanced_together": SB, "value": 2 * SB * ITERS_PER_SAMPLE / (time.perf_counter() - tb), "unit": "iters/s",
+                                         "note": "2 x (primal + 12 iterations) of 4 independent samples in one batch; not the headline value"}
+            del netb
+        except Exception as ex:                              # never lose the headline line to the extra leg
+            res["batched_throughput"] = {"error": str(ex)[:200]}
 
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference), fp32, same

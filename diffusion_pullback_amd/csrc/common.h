@@ -110,6 +110,39 @@ template <> struct Vec<f16> {
   }
 };
 
+// a 16-byte chunk held in registers between two phases of a kernel: raw bits <-> float[CH]
+template <typename T> struct Raw;
+template <> struct Raw<float> {
+  __device__ static inline void unpack(const uint4& r, float* o) { o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w); }
+  __device__ static inline uint4 pack(const float* o) { return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])); }
+};
+template <> struct Raw<bf16> {
+  __device__ static inline void unpack(const uint4& r, float* o) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  __device__ static inline uint4 pack(const float* o) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+template <> struct Raw<f16> {
+  __device__ static inline void unpack(const uint4& r, float* o) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = h2f((unsigned short)(w[i] & 0xffffu)); o[2 * i + 1] = h2f((unsigned short)(w[i] >> 16)); }
+  }
+  __device__ static inline uint4 pack(const float* o) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2h(o[2 * i]) | ((unsigned)f2h(o[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
 // 16-bit flavour of the specialised MFMA kernels (LDS-ring GEMMs, halo convolution, fused attention).  Those kernels only move
 // 16-bit words except at three places -- the MFMA opcode, fp32 -> 16-bit packing, 16-bit -> fp32 unpacking -- so they keep ONE
 // raw storage type (struct bf16) and take the flavour as a template parameter: FL = 0 bfloat16, FL = 1 IEEE half.

@@ -77,7 +77,7 @@ struct dpb_engine {
   char* ws = nullptr;
   size_t ws_bytes = 0;
   // arena offsets
-  size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0;
+  size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0, gnpart = 0, gnpart_bytes = 0, gnticket = 0;
   size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20, zeros = 0;
   size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
   size_t temb_host_stage = 0;
@@ -267,6 +267,8 @@ int gn_run(dpb_engine* e, const Op& op, int mode, int n) {
   a.beta = (const float*)d.w[1];
   a.pstats = (double*)(e->ws + op.pstats);
   a.tstats = (double*)(e->ws + op.tstats);
+  a.part = (float*)(e->ws + e->gnpart); a.part_bytes = e->gnpart_bytes; a.ticket = (int*)(e->ws + e->gnticket);
+  a.det = gn_deterministic();
   a.HW = bi.rows; a.C = bi.C; a.G = d.ip[0]; a.silu = d.ip[1]; a.eps = d.fp[0];
   a.Bp = e->cur_batch;
   if (mode == MODE_PRIMAL) {
@@ -760,6 +762,18 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   for (auto& b : e->bufs) maxrc = std::max(maxrc, (size_t)b.rows * b.C);
   e->pstats_off = take(e->pstats_bytes);
   e->tstats_off = take(e->tstats_bytes);
+  {  // GroupNorm statistics scratch: one partial per (sample or tangent, block, group); a launch uses at most max(512, HW / 8) blocks in all
+    size_t need = 0;
+    for (auto& op : e->ops)
+      if (op.d.kind == DPB_OP_GROUPNORM) {
+        const size_t hw = e->bufs[op.d.in0].rows, nmax = (size_t)std::max(e->maxB, e->maxT);
+        const size_t blocks = std::max<size_t>(nmax * ((hw + 7) / 8), 1);          // ppb >= 8
+        need = std::max(need, std::min<size_t>(blocks, std::max<size_t>(1024, nmax * ((hw + 63) / 64))) * 2 * op.d.ip[0] * sizeof(float));
+      }
+    e->gnpart_bytes = need;
+    e->gnpart = take(need);
+    e->gnticket = take(sizeof(int) * (size_t)std::max(e->maxB, e->maxT));
+  }
   for (auto& op : e->ops)
     if (op.d.kind == DPB_OP_GROUPNORM) { op.pstats += e->pstats_off; op.tstats += e->tstats_off; }
   e->S1 = take(s1); e->S2 = take(s2); e->T1 = take(t1); e->Dv = take(dv); e->convtmp = take(ctmp);
@@ -832,7 +846,7 @@ int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* c
     e->n_launch++;
     if (int r = launch_nchw_to_nhwc(e->dtype, stage, e->P(e->temb_buf), 1, (int)emb.size(), 1, (int)emb.size(), e->stream)) return r;
   }
-  if (e->pstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));
+  if (e->pstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));   // atomic statistics path accumulates
   e->cur_batch = batch;
   const int last = e->producer[upto_buf];
   for (int i = 0; i <= last; ++i)
@@ -1009,6 +1023,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_kch")) kch = value;
   else if (!strcmp(key, "gemm_dma_auto")) { gemm_debug_dma_auto(value); return 0; }
   else if (!strcmp(key, "gemm_order")) { gemm_debug_order(value); return 0; }
+  else if (!strcmp(key, "gn_deterministic")) { gn_debug_deterministic(value); return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

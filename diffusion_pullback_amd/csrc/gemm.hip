@@ -495,8 +495,9 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   long s;
   if (g_force_splitk) s = g_force_splitk;
   else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
+    static const long target = getenv("DPB_SPLITK_TARGET") ? atol(getenv("DPB_SPLITK_TARGET")) : 512;   // tuning switch
     if (tiles >= 384) return 1;
-    s = std::max<long>(1, (512 + tiles / 2) / tiles);
+    s = std::max<long>(1, (target + tiles / 2) / tiles);
     s = std::min<long>(s, std::max(1, nk / 16));
   } else {
     if (tiles >= 256 || nk < 64) return 1;      // only when CUs would idle and K is long enough to amortise the slabs

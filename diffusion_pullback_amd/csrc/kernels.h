@@ -54,6 +54,8 @@ int gemm_uses_halo(int dtype, const GemmArgs& a);
 int gemm_epi_supported(int dtype, const GemmArgs& a);   // can this launch take GemmArgs::epi != EPI_PLAIN?
 int gemm_uses_dma(int dtype, const GemmArgs& a);   // 0 = register-staged kernel, else the tile code for launch_gemm_dma
 void gemm_debug_dma_auto(int on);
+void gn_debug_deterministic(int on);
+int gn_deterministic();
 void gemm_debug_order(int o);   // -1 heuristic, 0 A-major, 1 B-major
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64
 
@@ -66,6 +68,10 @@ struct GNArgs {
   const float* gamma = nullptr; const float* beta = nullptr;
   double* pstats = nullptr;       // [Bp][G][2]  primal (sum, sumsq) -> finalised to (mean, rstd) in place
   double* tstats = nullptr;       // [NT][G][2]  tangent / adjoint sums
+  float* part = nullptr;          // per-block partial sums [n][blocks][G][2] (scratch shared by every GroupNorm launch of the stream)
+  size_t part_bytes = 0;
+  int* ticket = nullptr;          // [n] arrival counters, zero between launches
+  int det = 0;                    // 1: bitwise reproducible statistics (ordered reduction); 0: atomics (default, fastest)
   int Bp = 1, NT = 0, kps = 1;    // tangent j belongs to primal sample j / kps
   int HW = 0, C = 0, G = 32;
   float eps = 1e-5f;

@@ -1,8 +1,12 @@
 // GroupNorm(+SiLU) and LayerNorm for NHWC activations: primal, tangent (JVP) and adjoint (VJP wrt input).
 //
 // HBM-bound kernels.  Every thread owns a fixed 16-byte channel chunk (coalesced rows, per-channel
-// constants loaded once) and walks pixels.  GroupNorm: pass 1 accumulates per-(sample,group) sums
-// (LDS float atomics per block -> one fp64 global atomic per group per block), pass 2 applies.
+// constants loaded once) and walks pixels.  GroupNorm: pass 1 accumulates per-(sample,group) sums, pass 2 applies.
+// Two statistics paths for the two-pass kernels: the default adds block partials with LDS float atomics + one fp64 global atomic per group
+// per block (fastest; the order of the adds varies from run to run); GNArgs::det = 1 (dpb_debug_set("gn_deterministic", 1)) reduces a
+// block's per-channel partials through LDS in a fixed order, publishes one partial per group with write-through stores, and the block
+// that arrives last at a ticket counter adds all partials in block order in fp64 -- bitwise reproducible runs, ~10 % slower end to end.
+// Feature maps whose per-sample group window fits a block's registers use the ONE-launch kernel below (deterministic by construction).
 // The tangent and adjoint share one algebraic form:
 //     out = rstd * (v - mean(v) - xhat * mean(xhat * v))
 // with v = dx (tangent; gamma and SiLU' applied after) or v = gamma * SiLU'(y) * gz (adjoint; before).
@@ -11,10 +15,16 @@
 
 namespace dpb {
 
+static int g_gn_det = getenv("DPB_GN_DETERMINISTIC") ? atoi(getenv("DPB_GN_DETERMINISTIC")) : 0;
+void gn_debug_deterministic(int on) { g_gn_det = on; }
+int gn_deterministic() { return g_gn_det; }
+
 template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
   constexpr int CH = TT<T>::CH;
-  __shared__ float lsum[2 * 256];   // up to 256 groups... G <= 128 used: [G][2]
+  extern __shared__ float lch[];    // STATS, deterministic path: per-channel partial sums [rpi][C][2] (dynamic: rpi * C * 8 bytes)
+  __shared__ float lsum[2 * 256];   // STATS, atomic path: [G][2]
+  __shared__ int s_last;
   const int tid = threadIdx.x;
   const int j = blockIdx.y;                       // sample (primal) or tangent index
   const int b = (MODE == MODE_PRIMAL) ? j : j / a.kps;
@@ -27,7 +37,7 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
   const int p0 = blockIdx.x * ppb;
   const int p1 = min(p0 + ppb, a.HW);
   const double inv_n = 1.0 / ((double)a.HW * cpg);
-  if (STATS) {
+  if (STATS && !a.det) {
     for (int i = tid; i < 2 * a.G; i += 256) lsum[i] = 0.f;
     __syncthreads();
   }
@@ -117,7 +127,13 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
           Vec<T>::store(yp, o);
         }
       }
-      if (STATS) {
+      if (STATS && a.det) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          lch[((long)r * a.C + ch0 + e) * 2] = s1[e];
+          lch[((long)r * a.C + ch0 + e) * 2 + 1] = s2[e];
+        }
+      } else if (STATS) {
         // a 16-byte chunk spans at most a few groups: combine equal-group channels in registers first, so a thread
         // issues one pair of LDS atomics per group it touches instead of one pair per channel
         float g1 = s1[0], g2 = s2[0];
@@ -135,11 +151,226 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
       }
     }
   }
-  if (STATS) {
+  if (STATS && !a.det) {
     __syncthreads();
     double* dst = (MODE == MODE_PRIMAL) ? a.pstats : a.tstats;
     for (int i = tid; i < 2 * a.G; i += 256) atomicAdd(&dst[(long)j * a.G * 2 + i], (double)lsum[i]);
   }
+  if (STATS && a.det) {
+    __syncthreads();
+    // ordered in-block reduction: thread i < 2G adds the rpi x cpg per-channel partials of its group, always in the same order
+    const int nblk = gridDim.x;
+    float* part = a.part + ((long)j * nblk + blockIdx.x) * 2 * a.G;
+    for (int i = tid; i < 2 * a.G; i += 256) {
+      const int g = i >> 1, w = i & 1;
+      float acc = 0.f;
+      for (int rr = 0; rr < rpi; ++rr)
+        for (int c = 0; c < cpg; ++c) acc += lch[((long)rr * a.C + g * cpg + c) * 2 + w];
+      __hip_atomic_store(part + i, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1) store: no L2 write-back fence needed
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this CU before the ticket is taken
+    __syncthreads();
+    if (tid == 0) {
+      const int t = atomicAdd(a.ticket + j, 1);
+      s_last = (t == nblk - 1);
+      if (s_last) a.ticket[j] = 0;           // ready for the next launch on this stream
+    }
+    __syncthreads();
+    if (s_last) {                            // the last block to arrive adds every block's partial in block order (fp64)
+      double* dst = (MODE == MODE_PRIMAL) ? a.pstats : a.tstats;
+      const float* pj = a.part + (long)j * nblk * 2 * a.G;
+      for (int i = tid; i < 2 * a.G; i += 256) {
+        double acc = 0.0;
+        for (int bb = 0; bb < nblk; ++bb) acc += (double)__hip_atomic_load(pj + (long)bb * 2 * a.G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 loads: L1 bypassed
+        dst[(long)j * a.G * 2 + i] = acc;
+      }
+      if (MODE == MODE_PRIMAL) {             // finalise (sum, sum of squares) -> (mean, rstd) in place
+        __syncthreads();
+        for (int g = tid; g < a.G; g += 256) {
+          double* st = a.pstats + ((long)j * a.G + g) * 2;
+          const double m = st[0] * inv_n;
+          double v = st[1] * inv_n - m * m;
+          if (v < 0) v = 0;
+          st[0] = m;
+          st[1] = 1.0 / sqrt(v + (double)a.eps);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm in ONE launch (small feature maps)
+// A block owns GC whole groups -- a contiguous window of CW = GC * C/G channels -- of one sample / tangent and keeps its x (and v)
+// chunks in registers between the statistics phase and the apply phase: one read of every input instead of two, one launch instead of
+// two, and a fixed-order block reduction.  Used when the window of one sample fits the block's registers (8x8 ... 32x32 levels of the
+// U-Nets); larger maps take the two-pass kernels above.
+template <typename T, int MODE, int MAXC>
+__global__ __launch_bounds__(512) void gn_fused_kernel(GNArgs a, int GC) {
+  constexpr int CH = TT<T>::CH, NT = 512;
+  __shared__ float red[4][NT];          // per-thread partials: [slot * 2 + stat][thread]
+  __shared__ float seg[4 * 64 * 8];     // per (statistic, chunk column): 8 row-segment sums
+  __shared__ double colsum[4][64];      // per chunk column of the window
+  __shared__ float gst[2][64];          // per group of the window: the two statistics (means)
+  __shared__ double gsum[2][32];        // primal: raw fp64 group sums awaiting (mean, rstd)
+  const int tid = threadIdx.x;
+  const int j = blockIdx.y, b = (MODE == MODE_PRIMAL) ? j : j / a.kps;
+  const int cpg = a.C / a.G, CW = GC * cpg, CPC = CW / CH;
+  const int gbase = blockIdx.x * GC, ch_base = gbase * cpg;
+  const int ppi = NT / CPC, NTa = ppi * CPC;                 // pixels per sweep, active threads
+  const bool active = tid < NTa;
+  const int c = tid % CPC, pr = tid / CPC;
+  const int ch0 = ch_base + c * CH;
+  const int g0 = ch0 / cpg;                                    // the chunk touches groups g0 and (maybe) g0 + 1   (cpg >= CH)
+  const int split = (g0 + 1) * cpg - ch0;                      // elements e >= split belong to g0 + 1
+  const double inv_n = 1.0 / ((double)a.HW * cpg);
+  float gam[CH], bet[CH];
+  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+  if (active) {
+    Vec<float>::load(a.gamma + ch0, gam);
+    Vec<float>::load(a.beta + ch0, bet);
+    if constexpr (CH == 8) { Vec<float>::load(a.gamma + ch0 + 4, gam + 4); Vec<float>::load(a.beta + ch0 + 4, bet + 4); }
+    if (MODE != MODE_PRIMAL) {
+      const int g1 = min(g0 + 1, a.G - 1);
+      mean[0] = (float)a.pstats[((long)b * a.G + g0) * 2]; rstd[0] = (float)a.pstats[((long)b * a.G + g0) * 2 + 1];
+      mean[1] = (float)a.pstats[((long)b * a.G + g1) * 2]; rstd[1] = (float)a.pstats[((long)b * a.G + g1) * 2 + 1];
+    }
+  }
+  uint4 xr[MAXC], dr[MAXC];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};                           // [slot][stat]
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int p = pr + i * ppi;
+    if (active && p < a.HW) {
+      xr[i] = *reinterpret_cast<const uint4*>((const T*)a.x + ((long)b * a.HW + p) * a.C + ch0);
+      if (MODE != MODE_PRIMAL) dr[i] = *reinterpret_cast<const uint4*>((const T*)a.d + ((long)j * a.HW + p) * a.C + ch0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int p = pr + i * ppi;
+    if (active && p < a.HW) {
+      float x[CH], d[CH];
+      Raw<T>::unpack(xr[i], x);
+      if (MODE != MODE_PRIMAL) Raw<T>::unpack(dr[i], d);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const int hi = e >= split ? 1 : 0;
+        if (MODE == MODE_PRIMAL) {
+          s[hi * 2] += x[e];
+          s[hi * 2 + 1] += x[e] * x[e];
+        } else {
+          const float xh = (x[e] - mean[hi]) * rstd[hi];
+          const float y = gam[e] * xh + bet[e];
+          const float act = a.silu ? dsilu_(y) : 1.f;
+          const float v = (MODE == MODE_TANGENT) ? d[e] : gam[e] * act * d[e];
+          s[hi * 2] += v;
+          s[hi * 2 + 1] += xh * v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[q][tid] = active ? s[q] : 0.f;
+  __syncthreads();
+  // column sums over the block's pixel rows in two fixed-order stages (8 segments of rows, then the 8 segment sums): a single serial
+  // sweep of up to 102 dependent LDS reads per column cost more than the rest of the kernel
+  {
+    const int nseg = 8, seg_len = (ppi + nseg - 1) / nseg;
+    if (tid < 4 * CPC * nseg) {
+      const int sg = tid % nseg, qc = tid / nseg, q = qc / CPC, col = qc % CPC;
+      float acc = 0.f;
+      const int r0 = sg * seg_len, r1 = min(r0 + seg_len, ppi);
+      for (int r = r0; r < r1; ++r) acc += red[q][col + CPC * r];
+      seg[qc * nseg + sg] = acc;
+    }
+    __syncthreads();
+    if (tid < 4 * CPC) {
+      const int q = tid / CPC, col = tid % CPC;
+      double acc = 0.0;
+#pragma unroll
+      for (int sg = 0; sg < nseg; ++sg) acc += (double)seg[tid * nseg + sg];
+      colsum[q][col] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * GC) {                                         // group sums over the chunk columns, in column order
+    const int gl = tid >> 1, w = tid & 1;
+    double acc = 0.0;
+    for (int col = 0; col < CPC; ++col) {
+      const int cg = (ch_base + col * CH) / cpg - gbase;
+      if (cg == gl) acc += colsum[w][col];
+      if (cg + 1 == gl) acc += colsum[2 + w][col];
+    }
+    if (MODE == MODE_PRIMAL) {
+      gsum[w][gl] = acc;                                      // finalised below (needs both sums)
+    } else {
+      gst[w][gl] = (float)(acc * inv_n);
+    }
+  }
+  __syncthreads();
+  if (MODE == MODE_PRIMAL) {
+    if (tid < GC) {
+      const double m = gsum[0][tid] * inv_n;
+      double v = gsum[1][tid] * inv_n - m * m;
+      if (v < 0) v = 0;
+      const double rs = 1.0 / sqrt(v + (double)a.eps);
+      a.pstats[((long)j * a.G + gbase + tid) * 2] = m;
+      a.pstats[((long)j * a.G + gbase + tid) * 2 + 1] = rs;
+      gst[0][tid] = (float)m;
+      gst[1][tid] = (float)rs;
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  const int l0 = g0 - gbase, l1 = min(l0 + 1, GC - 1);
+  const float t1[2] = {gst[0][l0], gst[0][l1]}, t2[2] = {gst[1][l0], gst[1][l1]};   // primal: (mean, rstd); else (mean v, mean xhat v)
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int p = pr + i * ppi;
+    if (p < a.HW) {
+      float x[CH], d[CH], o[CH];
+      Raw<T>::unpack(xr[i], x);
+      if (MODE != MODE_PRIMAL) Raw<T>::unpack(dr[i], d);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const int hi = e >= split ? 1 : 0;
+        if (MODE == MODE_PRIMAL) {
+          const float y = (x[e] - t1[hi]) * t2[hi] * gam[e] + bet[e];
+          o[e] = a.silu ? silu_(y) : y;
+        } else {
+          const float xh = (x[e] - mean[hi]) * rstd[hi];
+          const float y = gam[e] * xh + bet[e];
+          const float act = a.silu ? dsilu_(y) : 1.f;
+          const float v = (MODE == MODE_TANGENT) ? d[e] : gam[e] * act * d[e];
+          const float w = rstd[hi] * (v - t1[hi] - xh * t2[hi]);
+          o[e] = (MODE == MODE_TANGENT) ? gam[e] * act * w : w;
+        }
+      }
+      T* yp = (T*)a.y + ((long)j * a.HW + p) * a.C + ch0;
+      if (a.accumulate) {
+        float old[CH];
+        Vec<T>::load(yp, old);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) o[e] += old[e];
+      }
+      *reinterpret_cast<uint4*>(yp) = Raw<T>::pack(o);
+    }
+  }
+}
+
+// window of GC groups for the one-launch kernel: the narrowest 16-byte aligned window of >= 64 bytes whose pixels fit 16 chunks per thread
+static int gn_fused_groups(int C, int G, int HW, int CH, int es) {
+  static const int on = getenv("DPB_GN_FUSED") ? atoi(getenv("DPB_GN_FUSED")) : 1;   // tuning switch (0: always two passes)
+  const int cpg = C / G;
+  if (!on || cpg < CH) return 0;
+  for (int gc = 1; gc <= G && gc <= 32; gc <<= 1) {
+    const int cw = gc * cpg;
+    if (G % gc || cw % CH || cw * es < 64 || cw / CH > 16) continue;      // (4 statistics x chunk columns x 8 row segments <= 512 threads)
+    const int cpc = cw / CH, ppi = 512 / cpc;
+    if (ppi < 1) return 0;
+    return (HW + ppi - 1) / ppi <= 16 ? gc : 0;
+  }
+  return 0;
 }
 
 __global__ void gn_finalize(double* st, int n_groups, double inv_n, double eps) {
@@ -157,15 +388,33 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
   if (a.C % CH || a.C % a.G || a.G > 256) { set_error("groupnorm: C=%d G=%d unsupported", a.C, a.G); return -1; }
   const int n = (MODE == MODE_PRIMAL) ? a.Bp : a.NT;
+  if (const int gc = gn_fused_groups(a.C, a.G, a.HW, CH, (int)sizeof(T))) {
+    const int cpc = gc * (a.C / a.G) / CH, ppi = 512 / cpc, sweeps = (a.HW + ppi - 1) / ppi;
+    dim3 grid(a.G / gc, n);
+    if (sweeps <= 4) hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 4>), grid, dim3(512), 0, st, a, gc);
+    else if (sweeps <= 8) hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 8>), grid, dim3(512), 0, st, a, gc);
+    else hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 16>), grid, dim3(512), 0, st, a, gc);
+    DPB_CHECK(hipGetLastError());
+    return 0;
+  }
   int ppb = 64;
   static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;   // tuning override
   while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
   dim3 grid((a.HW + ppb - 1) / ppb, n);
-  hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), 0, st, a, ppb);
-  if (MODE == MODE_PRIMAL) {
+  size_t lds = 0;
+  if (a.det) {
+    const int cols = a.C / CH, cw = cols < 256 ? cols : 256, rpi = 256 / cw;
+    lds = (size_t)rpi * a.C * 2 * sizeof(float);
+    if (!a.part || !a.ticket || (size_t)grid.x * n * 2 * a.G * sizeof(float) > a.part_bytes) {
+      set_error("groupnorm: statistics scratch missing or too small (%u blocks x %d x %d groups)", grid.x, n, a.G);
+      return -1;
+    }
+    if (lds > 48 * 1024) { set_error("groupnorm: C=%d needs %zu bytes of LDS for the ordered reduction", a.C, lds); return -1; }
+  }           // (atomic path: the caller has zeroed pstats / tstats -- one memset per pass in the engine)
+  hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), lds, st, a, ppb);
+  if (MODE == MODE_PRIMAL && !a.det) {
     int ng = a.Bp * a.G;
-    hipLaunchKernelGGL(gn_finalize, dim3((ng + 255) / 256), dim3(256), 0, st, a.pstats, ng,
-                       1.0 / ((double)a.HW * (a.C / a.G)), (double)a.eps);
+    hipLaunchKernelGGL(gn_finalize, dim3((ng + 255) / 256), dim3(256), 0, st, a.pstats, ng, 1.0 / ((double)a.HW * (a.C / a.G)), (double)a.eps);
   }
   hipLaunchKernelGGL((gn_kernel<T, MODE, false>), grid, dim3(256), 0, st, a, ppb);
   DPB_CHECK(hipGetLastError());

@@ -145,7 +145,8 @@ int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* tot
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
 /* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
  * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..517: BK=64 rings; 600: halo-tile 3x3 convolution), "gemm_splitk" (n),
- * "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block order per XCD). */
+ * "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block order per XCD), "gn_deterministic" (0|1: GroupNorm
+ * statistics of the two-pass kernels reduced in a fixed order -> bitwise reproducible runs, ~10 % slower; default 0 = atomics). */
 int dpb_debug_set(const char* key, int value);
 
 #ifdef __cplusplus

@@ -53,13 +53,13 @@ def test_gather_bases_on_nccl_world_size_1():
 
 
 def test_bench_under_torchrun_matches_plain_run():
-    common = ["--gpus", "1", "--steps", "24", "--warmup", "12", "--workload", "toy", "--k", "3", "--no-cpu-baseline", "--no-roofline"]
+    common = ["--gpus", "1", "--steps", "240", "--warmup", "12", "--workload", "toy", "--k", "3", "--no-cpu-baseline", "--no-roofline"]
     plain = _bench(common)
     tr = _bench(common, torchrun=True)
     assert plain["config"]["rccl_world_size"] == 0 and tr["config"]["rccl_world_size"] == 1
     assert plain["scaling"] == tr["scaling"] == "weak" and plain["finite"] and tr["finite"] and plain["n_gpus"] == tr["n_gpus"] == 1
     assert all(abs(a - b) <= 3e-2 * abs(a) for a, b in zip(plain["s_top"], tr["s_top"])), (plain["s_top"], tr["s_top"])
-    assert 0.4 < tr["value"] / plain["value"] < 2.5, (tr["value"], plain["value"])     # same job + one world_size-1 all_gather
+    assert 0.5 < tr["value"] / plain["value"] < 2.0, (tr["value"], plain["value"])     # same 20-sample job + one world_size-1 packed all_gather
 
 
 def test_bench_strong_scaling_mode_shards_samples():

@@ -67,3 +67,28 @@ def test_timestep_forms_and_chunking_agree(toy):
                                           convergence_threshold=1e-9, V0=V0) for c in (25, 2, 3)]     # 1, 3 and 2 chunks
     for u, s, vT in outs[1:]:
         assert torch.allclose(s, outs[0][1], rtol=1e-4) and torch.allclose(vT, outs[0][2], atol=1e-4)
+
+
+def test_engine_is_bitwise_reproducible_in_deterministic_mode():
+    """dpb_debug_set("gn_deterministic", 1): no pass adds floating-point numbers in an order decided at run time (GroupNorm statistics of the
+    two-pass kernels are reduced in block order by the last-arriving block, the one-launch kernel and split-K slabs are ordered by
+    construction): repeated runs of the 16-bit engine give identical bits.  (Default: atomics in the two-pass statistics, ~10 % faster.)"""
+    import torch
+    from diffusion_pullback_amd import PullbackUNet
+    from diffusion_pullback_amd import lib as L
+    from oracle import unet_sd
+    L.check(L.load().dpb_debug_set(b"gn_deterministic", 1))
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=64, ctx_len=77)     # 64x64: two-pass GroupNorm; 32x32: one-launch kernel
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(2, 4, 64, 64, generator=g); ctx = torch.randn(2, 77, 768, generator=g)
+    net = PullbackUNet("sd", cfg, p, dtype=torch.bfloat16, device="cuda:0", max_batch=2, max_rank=6, upto=("mid", 0), verbose=False)
+    V0 = torch.linalg.qr(torch.randn(4 * 64 * 64, 3, generator=g))[0].T.contiguous()
+    runs = []
+    for _ in range(3):
+        _, s, V, _ = net.pullback_fixed(z, 696.2727, ctx, "mid", 0, 3, 3, V0)
+        runs.append((s.clone(), V.clone(), net.engine.read(("mid", 0)).clone()))
+    L.check(L.load().dpb_debug_set(b"gn_deterministic", 0))
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))

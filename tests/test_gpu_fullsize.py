@@ -209,7 +209,7 @@ def test_sd15_config3_k10_samples_advanced_together():
         _, s_i, V_i, _ = net.pullback_fixed(zs[i:i + 1], T_SD, ctx, "mid", 0, k, iters, V0)
         cos = abs_cos(V_b[k * i:k * (i + 1)], V_i)
         assert torch.allclose(s_b[k * i:k * (i + 1)], s_i, rtol=2e-2), (i, s_b[k * i:k * (i + 1)], s_i)
-        assert (cos > 0.99).all(), (i, cos)                                       # bf16 atomics in GroupNorm: not bitwise repeatable
+        assert (cos > 0.99).all(), (i, cos)                                       # (batched and single launches pick different split-K / tiles: not bitwise equal)
     # distinct samples have distinct bases (the batch is not one sample repeated)
     assert abs_cos(V_b[0:1], V_b[k:k + 1]).item() < 0.99
     e = net.engine

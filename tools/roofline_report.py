@@ -11,7 +11,7 @@ import sys
 
 DIR = sys.argv[1] if len(sys.argv) > 1 else "profiles"
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
-ITERS = float(sys.argv[3]) if len(sys.argv) > 3 else 36.0        # tools/refresh_profiles.sh: 12 warm-up + 24 timed iterations
+ITERS = float(sys.argv[3]) if len(sys.argv) > 3 else 48.0        # tools/gpu_session.sh: 12 warm-up + 36 timed iterations
 PEAK_TF, PEAK_HBM = 2500.0, 8.0                                    # bf16 dense MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
 KIND = {"0": "gemm_kernel", "1": "gemm_kernel", "2": "gemm_dma_kernel", "3": "gemm_dma_kernel", "4": "gemm_ring64_kernel", "5": "conv_halo_kernel"}
 
@@ -40,13 +40,22 @@ def main():
     for r in csv.DictReader(open(os.path.join(DIR, f"{TAG}_sd15_gemm_launches_hip_events.csv"))):
         f = KIND.get(r["big"], "gemm_kernel")
         flops[f] = flops.get(f, 0.0) + 2.0 * float(r["M"]) * float(r["N"]) * float(r["K"]) * float(r["Z"])
+    mfma = {}                                                       # family -> (MFMA busy cycles, SIMD-cycles available) from the SQ pass, if collected
+    pm = os.path.join(DIR, f"{TAG}_pmc_sd15_mid_k5_bf16.json")
+    if os.path.exists(pm):
+        for k, e in json.load(open(pm))["kernels"].items():
+            raw = e.get("raw", {})
+            if "GRBM_GUI_ACTIVE" in raw:
+                m = mfma.setdefault(family(k), [0.0, 0.0])
+                m[0] += raw.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * e["launches"]
+                m[1] += 1024.0 * raw["GRBM_GUI_ACTIVE"] / 8.0 * e["launches"]
     total = sum(v[0] for v in fam.values())
     print(f"# Roofline report, SD-1.5 mid-block, k = 5, bf16, one power iteration ({TAG})\n")
     print("Sources: `rocprofv3 --kernel-trace --stats` (time), separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (HBM bytes = "
           "(2·FETCH + WRITE)·1024), per-launch HIP events (GEMM shapes → algorithmic flops). Peaks: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM.")
     print(f"Kernel time per iteration: **{total:.2f} ms**.\n")
-    print("| kernel family | ms / iter | share | launches / iter | algorithmic TFLOP/s | % MFMA peak | HBM GB / iter | HBM TB/s | % HBM peak |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| kernel family | ms / iter | share | launches / iter | algorithmic TFLOP/s | % MFMA peak | MFMA pipe busy (PMC) | HBM GB / iter | HBM TB/s | % HBM peak |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for f, (ms, calls) in sorted(fam.items(), key=lambda x: -x[1][0]):
         if ms < 0.01:
             continue
@@ -54,8 +63,11 @@ def main():
         gb = hbm.get(f)
         tbs = gb / (ms * 1e-3) / 1e12 if gb else None
         print(f"| `{f}` | {ms:.3f} | {100 * ms / total:.1f} % | {calls / ITERS:.1f} | " + (f"{tf:.0f} | {100 * tf / PEAK_TF:.1f} % | " if tf else "– | – | ") +
+              (f"{100 * mfma[f][0] / mfma[f][1]:.1f} % | " if f in mfma and mfma[f][1] > 0 and mfma[f][0] > 0 else "– | ") +
               (f"{gb / 1e9:.2f} | {tbs:.2f} | {100 * tbs / PEAK_HBM:.0f} % |" if gb else "– | – | – |"))
     gemm_ms = sum(fam[f][0] for f in flops if f in fam)
+    print("\n'MFMA pipe busy' = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) from the separate SQ counter pass (issued MFMAs incl. padded "
+          "tile lanes; counter passes run ~1.4x slower than un-profiled ones, so it under-reads the un-profiled utilisation).")
     print(f"\nAll GEMM / convolution kernels together: {sum(flops.values()) / 1e12:.2f} TFLOP in {gemm_ms:.2f} ms = "
           f"{sum(flops.values()) / (gemm_ms * 1e-3) / 1e12:.0f} TFLOP/s ({100 * sum(flops.values()) / (gemm_ms * 1e-3) / 1e12 / PEAK_TF:.1f} % of the MFMA peak); "
           f"the attention kernels' flops are not in the per-launch CSV (5 / 7 L×L×d products per tangent / cotangent and head).")

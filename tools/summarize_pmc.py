@@ -1,8 +1,10 @@
 """Per-kernel PMC summary of tools/pmc_mfma.sh:  python tools/summarize_pmc.py gpurun_out TAG  -> gpurun_out/TAG_pmc_mfma.json + a table.
 
-MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE): the share of SIMD-cycles with the matrix pipe
-busy while the kernel ran (SQ_VALU_MFMA_BUSY_CYCLES counts cycles, 32 per v_mfma_f32_32x32x16 -- MI355X_MICROARCH.md; the SQ_WAIT_* /
-SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* counters count quad-cycles and are reported as shares of SQ_WAVE_CYCLES).
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): the share of SIMD-cycles with the matrix pipe
+busy while the kernel ran.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles, 32 per v_mfma_f32_32x32x16 (checked: = 32 x SQ_INSTS_MFMA in every
+row); rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (8 x the kernel's duration in cycles, checked against the kernel trace),
+hence the / 8.  The SQ_WAIT_* / SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* counters count quad-cycles and are reported as shares of SQ_WAVE_CYCLES.
+Counter passes run ~1.4x slower than un-profiled ones (clock + collection), so the utilisation is a lower bound of the un-profiled value.
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction of the guide)."""
 import csv
 import glob
@@ -40,7 +42,7 @@ def main():
         act = g("GRBM_GUI_ACTIVE")
         wc = g("SQ_WAVE_CYCLES") or 1.0
         e = {"launches": launches, "gui_active_cycles_per_launch": act / max(launches, 1),
-             "mfma_util": g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * act) if act else None,
+             "mfma_util": g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * act / 8.0) if act else None,
              "wait_inst_any_share": g("SQ_WAIT_INST_ANY") / wc, "wait_any_share": g("SQ_WAIT_ANY") / wc, "active_inst_any_share": g("SQ_ACTIVE_INST_ANY") / wc,
              "raw": {n: v[1] / max(v[0], 1) for n, v in c.items()}}
         if k in sq2:
