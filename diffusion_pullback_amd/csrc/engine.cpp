@@ -287,7 +287,7 @@ int gn_run(dpb_engine* e, const Op& op, int mode, int n) {
       e->ginit[d.in0] = 1;
     }
   }
-  e->n_launch += 2;
+  e->n_launch += groupnorm_launches(e->dtype, mode, a);
   return launch_groupnorm(e->dtype, mode, a, e->stream);
 }
 

@@ -78,6 +78,7 @@ struct GNArgs {
   int silu = 0, accumulate = 0;
 };
 int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st);
+int groupnorm_launches(int dtype, int mode, const GNArgs& a);
 
 struct LNArgs {
   const void* x = nullptr; const void* d = nullptr; void* y = nullptr;

@@ -358,7 +358,9 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(GNArgs a, int GC) {
   }
 }
 
-// window of GC groups for the one-launch kernel: the narrowest 16-byte aligned window of >= 64 bytes whose pixels fit 16 chunks per thread
+// window of GC groups for the one-launch kernel: the narrowest 16-byte aligned window of >= 64 bytes whose pixels fit 4 chunks per thread
+// (measured, profiles/r02_*: 8x8 / 16x16 maps 6-10 us against 2 x 7 us for the two passes; at 32x32 only 40-80 blocks carry 16 chunks per
+// thread and the launch takes 24-32 us against 18 us -- those maps stay on the two-pass kernels)
 static int gn_fused_groups(int C, int G, int HW, int CH, int es) {
   static const int on = getenv("DPB_GN_FUSED") ? atoi(getenv("DPB_GN_FUSED")) : 1;   // tuning switch (0: always two passes)
   const int cpg = C / G;
@@ -368,7 +370,7 @@ static int gn_fused_groups(int C, int G, int HW, int CH, int es) {
     if (G % gc || cw % CH || cw * es < 64 || cw / CH > 16) continue;      // (4 statistics x chunk columns x 8 row segments <= 512 threads)
     const int cpc = cw / CH, ppi = 512 / cpc;
     if (ppi < 1) return 0;
-    return (HW + ppi - 1) / ppi <= 16 ? gc : 0;
+    return (HW + ppi - 1) / ppi <= 4 ? gc : 0;
   }
   return 0;
 }
@@ -391,9 +393,8 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
   if (const int gc = gn_fused_groups(a.C, a.G, a.HW, CH, (int)sizeof(T))) {
     const int cpc = gc * (a.C / a.G) / CH, ppi = 512 / cpc, sweeps = (a.HW + ppi - 1) / ppi;
     dim3 grid(a.G / gc, n);
-    if (sweeps <= 4) hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 4>), grid, dim3(512), 0, st, a, gc);
-    else if (sweeps <= 8) hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 8>), grid, dim3(512), 0, st, a, gc);
-    else hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 16>), grid, dim3(512), 0, st, a, gc);
+    if (sweeps > 4) { set_error("groupnorm: %d sweeps exceed the one-launch kernel's register window", sweeps); return -1; }
+    hipLaunchKernelGGL((gn_fused_kernel<T, MODE, 4>), grid, dim3(512), 0, st, a, gc);
     DPB_CHECK(hipGetLastError());
     return 0;
   }
@@ -419,6 +420,11 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gn_kernel<T, MODE, false>), grid, dim3(256), 0, st, a, ppb);
   DPB_CHECK(hipGetLastError());
   return 0;
+}
+
+int groupnorm_launches(int dtype, int mode, const GNArgs& a) {   // kernels launch_groupnorm issues (engine statistics)
+  if (gn_fused_groups(a.C, a.G, a.HW, dt_chunk(dtype), dtype == DT_F32 ? 4 : 2)) return 1;
+  return (mode == MODE_PRIMAL && !a.det) ? 3 : 2;
 }
 
 int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st) {
