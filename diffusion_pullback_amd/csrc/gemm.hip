@@ -482,13 +482,13 @@ int gemm_epi_supported(int dtype, const GemmArgs& a) {
   if (dtype == DT_F32 || a.Z1 * a.Z2 != 1 || a.gather != GATHER_NONE || a.N % 128 || a.M <= 0) return 0;
   if (a.epi == EPI_GEGLU_ADJ && a.N % 64) return 0;
   const int dt = gemm_uses_dma(dtype, a);
-  return dt == 128 || dt == 130 || dt == 132 || dt == 256 || dt >= 512;
+  return dt == 128 || dt == 130 || dt == 132 || dt == 256 || (dt >= 512 && dt <= 517);
 }
 
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256 || tile >= 512) ? 128 : 64;
+  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517)) ? 128 : 64;
   const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517) ? 256 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;

@@ -37,8 +37,11 @@ __device__ inline bf16x8 lds_read_frag(unsigned addr) {
 // threaded through it as read-write operands
 template <int N, int NA, int NB>
 __device__ inline void wait_frags(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
-  static_assert((NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2), "fragment counts of the supported wave tiles");
-  if constexpr (NA == 2 && NB == 2) {
+  static_assert((NA == 1 || NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2), "fragment counts of the supported wave tiles");
+  if constexpr (NA == 1) {
+    static_assert(NB == 1, "64x64 tile: one fragment each");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(N));
+  } else if constexpr (NA == 2 && NB == 2) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
   } else if constexpr (NA == 2 && NB == 1) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]) : "n"(N));
@@ -308,6 +311,8 @@ static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 
 // tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),
 // 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB).
+// (64x64 tiles on this ring for the small 1280^3 / 320x1280x1280 products: measured equal to the BK=32 64x64 ring within 0.3 % end to end --
+// those launches are latency-bound, not DMA-bound; removed.)
 // (320x128 / 320x64 tiles -- the M = 64 k rows of the 8x8-level layers at k = 5 in ONE tile, weight panel streamed once -- were built
 // and measured in round 2: one 4-wave block per CU is latency-bound, 47-52 us against 41 us for 128x128 S2 with split-K 8; removed.)
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
