@@ -27,8 +27,8 @@ namespace dpb {
 constexpr int att_waves(int d) { return d > 80 ? 4 : 8; }   // waves per block: 8 x 32 = 256 outer rows share every streamed tile
                                                             // (head dim 160: 4 waves, the fragments need the 512-register budget)
 
-template <int D> struct FA {
-  static constexpr int WAVES = att_waves(D), NT = WAVES * 64;
+template <int D, int W = att_waves(D)> struct FA {
+  static constexpr int WAVES = W, NT = WAVES * 64;
   static constexpr int NS = (D + 15) / 16;      // k-steps of the score products
   static constexpr int DP = NS * 16;            // padded head dim (score products)
   static constexpr int ND = (D + 31) / 32;      // 32-wide output tiles over the head dim
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
 }
 
 // ------------------------------------------------------------------------------------------------ tangent
-template <int D, int FL>
-__global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
-  using F = FA<D>;
+template <int D, int FL, int W = att_waves(D)>   // W waves (32 outer rows each) per block
+__global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void attn_jvp_kernel(FusedArgs a) {
+  using F = FA<D, W>;
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * F::ROW_ELEMS];
   bf16* sK = sm; bf16* sdK = sK + F::ROW_ELEMS; bf16* sV = sdK + F::ROW_ELEMS; bf16* sdV = sV + F::ROW_ELEMS;   // V^T / dV^T fragments: LDS transpose reads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -282,17 +282,17 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_jvp_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float delta = 0.f;
-  RowRegs<D> rK, rdK, rV, rdV;
-  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(dKp, a.C, rdK, tid);
-  fetch_row<D>(Vp, a.C, rV, tid); fetch_row<D>(dVp, a.C, rdV, tid);
+  RowRegs<D, F::NT> rK, rdK, rV, rdV;
+  fetch_row<D, F::NT>(Kp, a.C, rK, tid); fetch_row<D, F::NT>(dKp, a.C, rdK, tid);
+  fetch_row<D, F::NT>(Vp, a.C, rV, tid); fetch_row<D, F::NT>(dVp, a.C, rdV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();                      // previous stage fully consumed
-    commit_row<D>(rK, sK, tid); commit_row<D>(rdK, sdK, tid); commit_row<D>(rV, sV, tid); commit_row<D>(rdV, sdV, tid);
+    commit_row<D, F::NT>(rK, sK, tid); commit_row<D, F::NT>(rdK, sdK, tid); commit_row<D, F::NT>(rV, sV, tid); commit_row<D, F::NT>(rdV, sdV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {               // prefetch the next stage under this stage's MFMAs
       const int k1 = k0 + F::BI;
-      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(dKp + (long)k1 * a.C, a.C, rdK, tid);
-      fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_row<D>(dVp + (long)k1 * a.C, a.C, rdV, tid);
+      fetch_row<D, F::NT>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, F::NT>(dKp + (long)k1 * a.C, a.C, rdK, tid);
+      fetch_row<D, F::NT>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_row<D, F::NT>(dVp + (long)k1 * a.C, a.C, rdV, tid);
     }
     // Fragment reads run one step ahead of their MFMAs (explicit software pipeline; the compiler otherwise sinks every
     // ds_read to just before its use and each MFMA group waits out the LDS latency): the second-stage V^T / dV^T
@@ -606,9 +606,9 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ adjoint, key-major (gK, gV)
-template <int D, int FL>
-__global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
-  using F = FA<D>;
+template <int D, int FL, int W = att_waves(D)>
+__global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
+  using F = FA<D, W>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
   __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
   bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS;     // Q^T / gO^T fragments come from these row tiles by LDS transpose reads
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
   for (int d = 0; d < F::ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
-  RowRegs<D> rQ, rgO;
+  RowRegs<D, F::NT> rQ, rgO;
   float st0 = 0.f, st1 = 0.f, st2 = 0.f;
   auto fetch_stats = [&](int q0) {       // per-query statistics of a stage, D_q = gO_q . O_q
     if (tid < F::BI) {
@@ -649,16 +649,16 @@ __global__ __launch_bounds__(FA<D>::NT, (D <= 40 ? 2 : 1)) void attn_adj_kv_kern
       st2 = dq;
     }
   };
-  fetch_row<D>(Qp, a.C, rQ, tid); fetch_row<D>(gOp, a.Co, rgO, tid);
+  fetch_row<D, F::NT>(Qp, a.C, rQ, tid); fetch_row<D, F::NT>(gOp, a.Co, rgO, tid);
   fetch_stats(0);
   for (int q0 = 0; q0 < a.L; q0 += F::BI) {
     __syncthreads();
-    commit_row<D>(rQ, sQ, tid); commit_row<D>(rgO, sgO, tid);
+    commit_row<D, F::NT>(rQ, sQ, tid); commit_row<D, F::NT>(rgO, sgO, tid);
     if (tid < F::BI) { sstat[0][tid] = st0; sstat[1][tid] = st1; sstat[2][tid] = st2; }
     __syncthreads();
     if (q0 + F::BI < a.L) {
       const int q1 = q0 + F::BI;
-      fetch_row<D>(Qp + (long)q1 * a.C, a.C, rQ, tid); fetch_row<D>(gOp + (long)q1 * a.Co, a.Co, rgO, tid);
+      fetch_row<D, F::NT>(Qp + (long)q1 * a.C, a.C, rQ, tid); fetch_row<D, F::NT>(gOp + (long)q1 * a.Co, a.Co, rgO, tid);
       fetch_stats(q1);
     }
 #pragma unroll
@@ -946,10 +946,28 @@ int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* sta
   return 0;
 }
 
+// Block size of the d = 40 tangent / key-major adjoint kernels.  With 8 waves (256 outer rows) a block streams every inner tile once for 256
+// rows, but the grid of the 64x64 level at k = 5 -- 16 x 40 blocks -- is 2.5 rounds of the 256 CUs: the third round runs half empty.  With 4 waves,
+// two blocks per CU, the 1280 blocks are two full rounds plus exactly one block per CU: measured +0.6 % end to end in one session (109.7 vs 109.1
+// iterations/s).  Grids that are whole rounds of 8-wave blocks (k = 10, several samples) keep 8 waves: forcing 4 there costs 3.7 % (83.8 -> 80.7).
+static int att_block_waves(int d, int L, int pairs) {
+  static const int force = getenv("DPB_ATTN_WAVES") ? atoi(getenv("DPB_ATTN_WAVES")) : 0;     // tuning switch (4 | 8)
+  if (d != 40 || L % 256) return att_waves(d);
+  if (force == 4 || force == 8) return force;
+  return ((long)(L / 256) * pairs) % 256 == 0 ? 8 : 4;
+}
+
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
   if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  if (att_block_waves(f.d, f.L, nt * f.H) == 4 && f.d == 40) {
+    dim3 g4(f.L / 128, nt * f.H);
+    if (f.fl) hipLaunchKernelGGL((attn_jvp_kernel<40, 1, 4>), g4, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_jvp_kernel<40, 0, 4>), g4, dim3(256), 0, st, a);
+    DPB_CHECK(hipGetLastError());
+    return 0;
+  }
+  dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
   DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_jvp_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -971,7 +989,13 @@ int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   } else {
     DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_q_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   }
-  DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_kv_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
+  if (att_block_waves(f.d, f.L, nt * f.H) == 4 && f.d == 40) {
+    dim3 g4(f.L / 128, nt * f.H);
+    if (f.fl) hipLaunchKernelGGL((attn_adj_kv_kernel<40, 1, 4>), g4, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_adj_kv_kernel<40, 0, 4>), g4, dim3(256), 0, st, a);
+  } else {
+    DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_kv_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
+  }
   DPB_CHECK(hipGetLastError());
   return 0;
 }
