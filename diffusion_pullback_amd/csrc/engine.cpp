@@ -114,12 +114,12 @@ void gemm_prep(dpb_engine* e, GemmArgs& a) {
 }
 
 int gemm(dpb_engine* e, GemmArgs a) {
-  e->n_launch++;
   gemm_prep(e, a);
   const double kk = (double)a.K + (a.A2 ? a.K2 : 0);
   e->flops += 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
-  if (!e->profiling) return launch_gemm(e->dtype, a, e->stream);
+  int nl = 1;                                   // kernels enqueued: the product itself (+ splitk_reduce_kernel for split-K launches)
+  if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl); e->n_launch += nl; return r; }
   dpb_engine::Prof p;
   p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring, 5: halo-tile 3x3 convolution
@@ -127,7 +127,8 @@ int gemm(dpb_engine* e, GemmArgs a) {
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));
   DPB_CHECK(hipEventRecord(p.a, e->stream));
-  int r = launch_gemm(e->dtype, a, e->stream);
+  int r = launch_gemm(e->dtype, a, e->stream, &nl);
+  e->n_launch += nl;
   DPB_CHECK(hipEventRecord(p.b, e->stream));
   e->prof.push_back(p);
   return r;

@@ -430,6 +430,7 @@ static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0, g_dma_auto = 1, g_fo
 void gemm_debug_order(int o) { g_force_order = o; }
 void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
+static thread_local int t_reduce_launched = 0;   // set by launch_t when a splitk_reduce_kernel launch followed the product
 
 int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
   // Register-staged kernel, measured on MI355X (tools/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt):
@@ -593,6 +594,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
         long total = (long)a.M * a.N / 4;
         unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+        t_reduce_launched = 1;
         DPB_CHECK(hipGetLastError());
       }
       return 0;
@@ -609,6 +611,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
       long total = (long)a.M * a.N * Z / 4;
       unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
       hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+      t_reduce_launched = 1;
       DPB_CHECK(hipGetLastError());
     }
     return 0;
@@ -626,15 +629,19 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     long total = (long)a.M * a.N * Z / 4;
     unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+    t_reduce_launched = 1;
   }
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
-int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches) {
   GemmArgs b = a;
   b.fl = dtype == DT_F16;           // 16-bit flavour of the specialised kernels (H16<fl>)
-  return DPB_DISPATCH_T(dtype, T, launch_t<T>(dtype, b, st));
+  t_reduce_launched = 0;
+  const int r = DPB_DISPATCH_T(dtype, T, launch_t<T>(dtype, b, st));
+  if (launches) *launches = 1 + t_reduce_launched;
+  return r;
 }
 
 }  // namespace dpb

@@ -42,7 +42,7 @@ struct GemmArgs {
   int fl = 0;                         // 16-bit flavour of the specialised kernels: 0 bf16, 1 f16 (filled in by launch_gemm)
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
-int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches = nullptr);   // *launches: kernels enqueued (1, or 2 with splitk_reduce_kernel)
 int gemm_uses_big_tile(int dtype, const GemmArgs& a);
 void gemm_debug_set(int tile, int splitk, int kch);
 int gemm_kch(const GemmArgs& a);

@@ -12,7 +12,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpb.so")
+LIB_PATH = os.environ.get("DPB_LIB") or os.path.join(_HERE, "libdpb.so")   # DPB_LIB: another build of the same ABI (same-session A/B of kernel variants)
 CSRC = os.path.join(_HERE, "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 STAMP_PATH = LIB_PATH + ".srchash"          # content hash of the sources the .so was built from (git-ignored, travels with gpurun)
@@ -119,7 +119,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if os.path.exists(HIPCC) and os.path.isdir(CSRC) and os.access(_HERE, os.W_OK) and _source_hash() != _built_hash():
+    if not os.environ.get("DPB_LIB") and os.path.exists(HIPCC) and os.path.isdir(CSRC) and os.access(_HERE, os.W_OK) and _source_hash() != _built_hash():
         # the sources changed since libdpb.so was linked (or it was never built): rebuild in-tree, incrementally -- an edited
         # .hip / dpb.h never runs against a stale binary, and never against a CPU substitute.  The stamp is a content hash, not
         # mtimes, so a copied tree (gpurun snapshot) with a matching .so does not rebuild.  One builder when several ranks
