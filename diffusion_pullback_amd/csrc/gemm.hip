@@ -462,6 +462,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
   if (g_force_tile >= 512 && g_force_tile <= 517) return g_force_tile;
+  if (g_force_tile == 518) return a.gather == GATHER_NONE && a.epi == EPI_PLAIN ? 518 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
@@ -471,8 +472,9 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // BK = 64 ring (gemm_ring64.hip: whole-line DMA + in-wave fragment prefetch, 128x128 tile, 2 stages -> 2 blocks/CU):
   // ahead of the BK = 32 rings by 10-35 % from ~8 stages of K on, with split-K when the tiles leave CUs idle
   if (a.K >= 512 && (t128 >= 200 || a.K >= 2048)) return 515;
-  // (3-stage ring = 48 KiB -> 3 blocks/CU measured slightly ahead of 4 stages / 2 blocks and 2 stages / 5 blocks)
-  if (t128 >= 400) return 130;                  // chip filled by 128x128 tiles
+  // short K (320 on the 64x64 level) with the chip filled by 128x128 tiles: the BK=64 ring again -- 11.5 vs 12.9 us on 20480x320x320,
+  // 27.9 vs 30.4 us at N = 960, equal at N >= 1280 (profiles/r02_gemm_shortk_microbench.txt); the BK=32 ring (130) remains for K % 64 != 0
+  if (t128 >= 400) return a.K % 64 == 0 ? 515 : 130;
   if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
   if (t64 >= 256) return 64;
   return 0;
@@ -483,21 +485,24 @@ int gemm_epi_supported(int dtype, const GemmArgs& a) {
   if (dtype == DT_F32 || a.Z1 * a.Z2 != 1 || a.gather != GATHER_NONE || a.N % 128 || a.M <= 0) return 0;
   if (a.epi == EPI_GEGLU_ADJ && a.N % 64) return 0;
   const int dt = gemm_uses_dma(dtype, a);
-  return dt == 128 || dt == 130 || dt == 132 || dt == 256 || (dt >= 512 && dt <= 517);
+  return dt == 128 || dt == 130 || dt == 132 || dt == 256 || (dt >= 512 && dt <= 517);   // (518: plain epilogue only)
 }
 
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517)) ? 128 : 64;
-  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517) ? 256 : T;
+  const int T = tile == 518 ? 256 : (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517)) ? 128 : 64;
+  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517 || tile == 518) ? 256 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;
   if (g_force_splitk) s = g_force_splitk;
   else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
     static const long target = getenv("DPB_SPLITK_TARGET") ? atol(getenv("DPB_SPLITK_TARGET")) : 512;   // tuning switch
-    if (tiles >= 384) return 1;
+    // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
+    // profiles/r02_gemm_split_microbench.txt (5120x640: K 1920 / 2560 24 / 32 us unsplit vs 34 / 41 us three-fold, K 5120 52 us two-fold vs
+    // 58 unsplit; 1280x3840x1280 25 vs 36 us; 320x10240x1280 18 vs 25 us)
+    if (tiles >= 192) return (tiles < 256 && nk >= 128) ? 2 : 1;
     s = std::max<long>(1, (target + tiles / 2) / tiles);
     s = std::min<long>(s, std::max(1, nk / 16));
   } else {

@@ -37,10 +37,12 @@ __device__ inline bf16x8 lds_read_frag(unsigned addr) {
 // threaded through it as read-write operands
 template <int N, int NA, int NB>
 __device__ inline void wait_frags(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
-  static_assert((NA == 1 || NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2), "fragment counts of the supported wave tiles");
+  static_assert((NA == 1 || NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2 || (NA == 2 && NB == 4)), "fragment counts of the supported wave tiles");
   if constexpr (NA == 1) {
     static_assert(NB == 1, "64x64 tile: one fragment each");
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(N));
+  } else if constexpr (NA == 2 && NB == 4) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
   } else if constexpr (NA == 2 && NB == 2) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
   } else if constexpr (NA == 2 && NB == 1) {
@@ -294,9 +296,11 @@ template <int BM, int BN, int S, int WAVES, int FL>
 static void launch_ring64_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
     case GATHER_NONE:
-      if (a.epi == EPI_GEGLU_TAN) hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_TAN>), grid, dim3(WAVES * 64), 0, st, a);
-      else if (a.epi == EPI_GEGLU_ADJ) hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_ADJ>), grid, dim3(WAVES * 64), 0, st, a);
-      else hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a);
+      if constexpr (BN == 128) {                  // the fused GEGLU epilogues pair the two 64-column waves of a 128-column tile
+        if (a.epi == EPI_GEGLU_TAN) { hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_TAN>), grid, dim3(WAVES * 64), 0, st, a); break; }
+        if (a.epi == EPI_GEGLU_ADJ) { hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_ADJ>), grid, dim3(WAVES * 64), 0, st, a); break; }
+      }
+      hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a);
       break;
     case GATHER_CONV: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONV, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
     case GATHER_CONVT: hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_CONVT, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a); break;
@@ -310,7 +314,8 @@ static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),
-// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB).
+// 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB),
+// 518 = 256x256 S2 with 8 waves (64x128 wave tiles, 128 KiB ring: half the L2->LDS bytes per flop of 128x128; plain epilogue only).
 // (64x64 tiles on this ring for the small 1280^3 / 320x1280x1280 products: measured equal to the BK=32 64x64 ring within 0.3 % end to end --
 // those launches are latency-bound, not DMA-bound; removed.)
 // (320x128 / 320x64 tiles -- the M = 64 k rows of the 8x8-level layers at k = 5 in ONE tile, weight panel streamed once -- were built
@@ -322,6 +327,11 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
   if (tile == 513) launch_ring64_t<256, 128, 3>(a, tiles(256, 128), st);
   else if (tile == 516) launch_ring64_t<256, 128, 3, 8>(a, tiles(256, 128), st);
   else if (tile == 517) launch_ring64_t<256, 128, 2, 8>(a, tiles(256, 128), st);
+  else if (tile == 518) {
+    if (a.epi != EPI_PLAIN || a.gather != GATHER_NONE) { set_error("gemm: the 256x256 ring tile takes plain-row operands and the plain epilogue only"); return -1; }
+    if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<256, 256, 2, GATHER_NONE, 8, 1>), tiles(256, 256), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_ring64_kernel<256, 256, 2, GATHER_NONE, 8, 0>), tiles(256, 256), dim3(512), 0, st, a);
+  }
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);
   else launch_ring64_t<128, 128, 3>(a, tiles(128, 128), st);
