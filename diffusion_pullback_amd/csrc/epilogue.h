@@ -43,6 +43,26 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
         for (int e = 0; e < 8; ++e) o[e] = p.alpha * (da[e] * ap[e] + dg[e] * gp[e]);      // ap = G1 = gelu(g), gp = G2 = a gelu'(g)
         H16<FL>::store8(C + (long)m * p.ldc + (n0 >> 1) + c8 * 8, o);
       }
+    } else if constexpr (WN == 128) {                          // 256x256 tile: the wave's own 128 columns are a | g of 64 hidden units
+      const int F2 = p.N;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int item = it * 64 + lane;
+        const int row = item >> 3, c8 = item & 7;
+        const int m = mrow0 + row;
+        const int n = n0 + wx * WN + c8 * 8;                   // interleaved column of the a-values (n0 % 256 == 0)
+        if (m >= p.M || n >= p.N) continue;
+        float da[8], dg[8], ap[8], gp[8], o[8];
+        Vec<float>::load(stage + row * SLD + c8 * 8, da); Vec<float>::load(stage + row * SLD + c8 * 8 + 4, da + 4);
+        Vec<float>::load(stage + row * SLD + 64 + c8 * 8, dg); Vec<float>::load(stage + row * SLD + 64 + c8 * 8 + 4, dg + 4);
+        const int smp = m / p.rows_per_sample, l = m - smp * p.rows_per_sample;
+        const bf16* hp = (const bf16*)p.hprim + ((long)(smp / p.epi_kps) * p.rows_per_sample + l) * F2 + n;
+        H16<FL>::load8(hp, ap);
+        H16<FL>::load8(hp + 64, gp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = p.alpha * (da[e] * ap[e] + dg[e] * gp[e]);
+        H16<FL>::store8(C + (long)m * p.ldc + ((n0 + wx * WN) >> 1) + c8 * 8, o);
+      }
     }
     return;
   }

@@ -462,19 +462,28 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (g_force_tile == 65) return 64;
   if (g_force_tile == 67) return 66;
   if (g_force_tile >= 512 && g_force_tile <= 517) return g_force_tile;
-  if (g_force_tile == 518) return a.gather == GATHER_NONE && a.epi == EPI_PLAIN ? 518 : 515;
+  if (g_force_tile == 518) return a.gather == GATHER_NONE ? 518 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
   // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
   // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
+  // 256x256 8-wave tile (half the L2->LDS bytes per flop): plain-row products that give >= 160 such tiles with < 7 % padding and K >= 640
+  // -- 12-26 % ahead of the 128x128 ring there, behind it below (profiles/r02_gemm_big_microbench.txt, r02_gemm_split_microbench.txt)
+  static const int big_env = getenv("DPB_TILE256") ? atoi(getenv("DPB_TILE256")) : 1;   // tuning switch
+  if (big_env && a.gather == GATHER_NONE && a.K >= 640 && a.Z1 * a.Z2 == 1) {
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    if (t256 >= 160 && (double)t256 * 65536.0 <= 1.07 * (double)a.M * a.N) return 518;
+  }
   // BK = 64 ring (gemm_ring64.hip: whole-line DMA + in-wave fragment prefetch, 128x128 tile, 2 stages -> 2 blocks/CU):
   // ahead of the BK = 32 rings by 10-35 % from ~8 stages of K on, with split-K when the tiles leave CUs idle
   if (a.K >= 512 && (t128 >= 200 || a.K >= 2048)) return 515;
   // short K (320 on the 64x64 level) with the chip filled by 128x128 tiles: the BK=64 ring again -- 11.5 vs 12.9 us on 20480x320x320,
   // 27.9 vs 30.4 us at N = 960, equal at N >= 1280 (profiles/r02_gemm_shortk_microbench.txt); the BK=32 ring (130) remains for K % 64 != 0
-  if (t128 >= 400) return a.K % 64 == 0 ? 515 : 130;
+  // -- up to ~1300 tiles; beyond (several samples advanced together: 81920 rows) the BK=32 ring's three blocks per CU hide the residual /
+  // row-bias loads of the epilogue better (43 vs 45 us on 81920x320x320 inside the pass)
+  if (t128 >= 400) return (a.K % 64 == 0 && t128 <= 1280) ? 515 : 130;
   if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
   if (t64 >= 256) return 64;
   return 0;
@@ -485,7 +494,8 @@ int gemm_epi_supported(int dtype, const GemmArgs& a) {
   if (dtype == DT_F32 || a.Z1 * a.Z2 != 1 || a.gather != GATHER_NONE || a.N % 128 || a.M <= 0) return 0;
   if (a.epi == EPI_GEGLU_ADJ && a.N % 64) return 0;
   const int dt = gemm_uses_dma(dtype, a);
-  return dt == 128 || dt == 130 || dt == 132 || dt == 256 || (dt >= 512 && dt <= 517);   // (518: plain epilogue only)
+  if (dt == 518) return a.N % 256 == 0;
+  return dt == 128 || dt == 130 || dt == 132 || dt == 256 || (dt >= 512 && dt <= 517);
 }
 
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)

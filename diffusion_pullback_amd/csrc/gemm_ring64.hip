@@ -315,7 +315,7 @@ static void launch_ring64_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 
 // tile codes: 512 = 128x128 S3 (96 KiB, 1 block/CU), 513 = 256x128 S3 (144 KiB), 514 = 128x128 S4, 515 = 128x128 S2 (2 blocks/CU),
 // 516 = 256x128 S3 with 8 waves (64x64 wave tiles, one shared B tile), 517 = the same with S2 (96 KiB),
-// 518 = 256x256 S2 with 8 waves (64x128 wave tiles, 128 KiB ring: half the L2->LDS bytes per flop of 128x128; plain epilogue only).
+// 518 = 256x256 S2 with 8 waves (64x128 wave tiles, 128 KiB ring: half the L2->LDS bytes per flop of 128x128; plain rows only).
 // (64x64 tiles on this ring for the small 1280^3 / 320x1280x1280 products: measured equal to the BK=32 64x64 ring within 0.3 % end to end --
 // those launches are latency-bound, not DMA-bound; removed.)
 // (320x128 / 320x64 tiles -- the M = 64 k rows of the 8x8-level layers at k = 5 in ONE tile, weight panel streamed once -- were built
@@ -328,9 +328,13 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
   else if (tile == 516) launch_ring64_t<256, 128, 3, 8>(a, tiles(256, 128), st);
   else if (tile == 517) launch_ring64_t<256, 128, 2, 8>(a, tiles(256, 128), st);
   else if (tile == 518) {
-    if (a.epi != EPI_PLAIN || a.gather != GATHER_NONE) { set_error("gemm: the 256x256 ring tile takes plain-row operands and the plain epilogue only"); return -1; }
-    if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<256, 256, 2, GATHER_NONE, 8, 1>), tiles(256, 256), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((gemm_ring64_kernel<256, 256, 2, GATHER_NONE, 8, 0>), tiles(256, 256), dim3(512), 0, st, a);
+    if (a.gather != GATHER_NONE) { set_error("gemm: the 256x256 ring tile takes plain-row operands only"); return -1; }
+    const dim3 g = tiles(256, 256);
+#define DPB_RING518(FLV, EPIV) hipLaunchKernelGGL((gemm_ring64_kernel<256, 256, 2, GATHER_NONE, 8, FLV, EPIV>), g, dim3(512), 0, st, a)
+    if (a.epi == EPI_GEGLU_TAN) { if (a.fl) DPB_RING518(1, EPI_GEGLU_TAN); else DPB_RING518(0, EPI_GEGLU_TAN); }
+    else if (a.epi == EPI_GEGLU_ADJ) { if (a.fl) DPB_RING518(1, EPI_GEGLU_ADJ); else DPB_RING518(0, EPI_GEGLU_ADJ); }
+    else { if (a.fl) DPB_RING518(1, EPI_PLAIN); else DPB_RING518(0, EPI_PLAIN); }
+#undef DPB_RING518
   }
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);

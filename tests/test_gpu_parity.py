@@ -348,11 +348,11 @@ def test_fused_geglu_epilogues_match_unfused_path(dtype, monkeypatch):
     p = unet_sd.init_params(cfg, seed=1)
     g = torch.Generator().manual_seed(2)
     z = torch.randn(1, 4, 64, 64, generator=g); ctx = torch.randn(1, 77, 768, generator=g)
-    V = torch.randn(3, 4 * 64 * 64, generator=g).cuda(); U = torch.randn(3, 640 * 32 * 32, generator=g).cuda()
-    tap = ("mid", 0)
+    V = torch.randn(5, 4 * 64 * 64, generator=g).cuda(); U = torch.randn(5, 640 * 32 * 32, generator=g).cuda()
+    tap = ("mid", 0)      # (5 tangents: the 32 x 32 level's FF products then run on the 256 x 256 ring tile, whose waves hold a | g of 64 units themselves)
 
     def run():
-        net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=1, max_rank=3, upto=tap, verbose=False)
+        net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=1, max_rank=5, upto=tap, verbose=False)
         net.engine.primal(z, 696.2727, ctx, tap)
         jv = net.engine.jvp(tap, V).clone(); nj = net.engine.stats()[0]
         ju = net.engine.vjp(tap, U).clone(); nv = net.engine.stats()[0]
