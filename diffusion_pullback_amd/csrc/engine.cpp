@@ -86,6 +86,14 @@ struct dpb_engine {
   std::vector<char> skip;           // ops whose work a fused epilogue of another op has done in the current pass
   long n_launch = 0;
   double flops = 0, gbytes = 0;
+  // captured power iteration (dpb_debug_set("graph_iterate", 1)), valid for one (tap, k, batch, buffer set)
+  struct GraphKey {
+    int tap, k, B; const void *V, *U, *s, *conv;
+    bool operator==(const GraphKey& o) const { return tap == o.tap && k == o.k && B == o.B && V == o.V && U == o.U && s == o.s && conv == o.conv; }
+  };
+  hipGraphExec_t gexec = nullptr;
+  GraphKey gkey{};
+  long g_launches = 0; double g_flops = 0, g_bytes = 0;
   // optional per-launch timing of the GEMM kernel (bench.py roofline leg); off in the timed region
   bool profiling = false;
   struct Prof { hipEvent_t a, b; double flops; int big; int M, N, K, Z, gather; };
@@ -792,7 +800,10 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   return 0;
 }
 
-void dpb_engine_destroy(dpb_engine* e) { delete e; }
+void dpb_engine_destroy(dpb_engine* e) {
+  if (e && e->gexec) (void)hipGraphExecDestroy(e->gexec);
+  delete e;
+}
 
 int dpb_engine_set_stream(dpb_engine* e, void* s) {
   if (!e) return fail("null engine");
@@ -912,6 +923,8 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
   return launch_orth(a, (hipStream_t)stream);
 }
 
+static int g_graph_iterate = 0;      // dpb_debug_set("graph_iterate", 1): replay the power iteration as a captured hipGraph (measurement option)
+
 int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, float* conv, int k, int n_iters) {
   if (!e || !V || !U || !s || !conv) return fail("null argument");
   if (k < 1 || k > 56) return fail("pca_rank k=%d outside [1,56]", k);
@@ -922,7 +935,7 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
   float* Wm = (float*)(e->ws + e->pbW);
   float* Vn = (float*)(e->ws + e->pbVn);
   long launches = 0; double fl = 0, gb = 0;
-  for (int it = 0; it < n_iters; ++it) {
+  auto body = [&]() -> int {                        // one power iteration: k JVPs, k VJPs, re-orthonormalisation, V <- V_new; no host sync
     if (int r = dpb_jvp(e, tap, V, nt, U)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
     if (int r = dpb_vjp(e, tap, U, nt, Wm)) return r;
@@ -932,7 +945,37 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
                            e->ws + e->orth + (size_t)b * sizeof(double) * (3 * 56 * 56 + 2), k, N, e->stream)) return r;
     DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * nt * N, hipMemcpyDeviceToDevice, e->stream));
     launches += 5 * B + 1;
+    return 0;
+  };
+  int it = 0;
+  if (g_graph_iterate && !e->profiling && e->stream != 0) {
+    // The launch sequence of an iteration is fixed for fixed (tap, k, batch, buffers): capture it once (after one eager iteration, so that
+    // every code object is loaded) and replay it.  Measured on MI355X: no gain -- the stream never runs dry.
+    const dpb_engine::GraphKey key{tap, k, B, V, U, s, conv};
+    if (!e->gexec || !(key == e->gkey)) {
+      if (int r = body()) return r;
+      ++it;
+      if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+      hipGraph_t g = nullptr;
+      const long l0 = launches; const double f0 = fl, b0 = gb;
+      DPB_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      const int r = body();
+      const hipError_t ce = hipStreamEndCapture(e->stream, &g);
+      e->g_launches = launches - l0; e->g_flops = fl - f0; e->g_bytes = gb - b0;
+      launches = l0; fl = f0; gb = b0;               // captured, not executed
+      if (r) { if (g) (void)hipGraphDestroy(g); return r; }
+      DPB_CHECK(ce);
+      DPB_CHECK(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      e->gkey = key;
+    }
+    for (; it < n_iters; ++it) {
+      DPB_CHECK(hipGraphLaunch(e->gexec, e->stream));
+      launches += e->g_launches; fl += e->g_flops; gb += e->g_bytes;
+    }
   }
+  for (; it < n_iters; ++it)
+    if (int r = body()) return r;
   e->n_launch = launches; e->flops = fl; e->gbytes = gb;
   return 0;
 }
@@ -1025,6 +1068,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_dma_auto")) { gemm_debug_dma_auto(value); return 0; }
   else if (!strcmp(key, "gemm_order")) { gemm_debug_order(value); return 0; }
   else if (!strcmp(key, "gn_deterministic")) { gn_debug_deterministic(value); return 0; }
+  else if (!strcmp(key, "graph_iterate")) { g_graph_iterate = value; return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

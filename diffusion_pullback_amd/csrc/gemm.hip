@@ -22,6 +22,9 @@
 // Small-M problems (8x8 feature maps: M = 64k rows) split K over blockIdx.z into
 // fp32 slabs that a second kernel reduces (weights stream from HBM exactly once).
 // Workgroup ids are remapped so that one XCD (= one L2) walks neighbouring tiles.
+#include <cstdio>
+#include <vector>
+
 #include "kernels.h"
 
 namespace dpb {
@@ -444,25 +447,54 @@ int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
   return t128 >= 1024;
 }
 
+// Per-shape tuning overrides, for in-pipeline kernel selection experiments (tools/gpu_gemm_override.py):
+//   DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..."   code as dpb_debug_set("gemm_tile"), split 0 = heuristic
+struct ShapeOverride { int M, N, K, gather, code, split; };
+static const std::vector<ShapeOverride>& shape_overrides() {
+  static const std::vector<ShapeOverride> v = [] {
+    std::vector<ShapeOverride> o;
+    const char* e = getenv("DPB_GEMM_OVERRIDE");
+    while (e && *e) {
+      ShapeOverride r{};
+      int used = 0;
+      if (sscanf(e, "%dx%dx%d:%d=%d/%d%n", &r.M, &r.N, &r.K, &r.gather, &r.code, &r.split, &used) == 6) o.push_back(r);
+      else break;
+      e += used;
+      if (*e == ',') ++e;
+    }
+    return o;
+  }();
+  return v;
+}
+static const ShapeOverride* find_override(const GemmArgs& a) {
+  for (const auto& r : shape_overrides())
+    if (r.M == a.M && r.N == a.N && r.K == a.K && r.gather == a.gather && a.Z1 * a.Z2 == 1) return &r;
+  return nullptr;
+}
+
 // the halo-tile 3x3 convolution (gemm_halo.hip): every supported shape of the path measured faster than the implicit-GEMM rings
 int gemm_uses_halo(int dtype, const GemmArgs& a) {
   static const int halo_env = getenv("DPB_CONV_HALO") ? atoi(getenv("DPB_CONV_HALO")) : 1;   // tuning switch (0: implicit-GEMM rings)
-  const bool want = g_force_tile == 600 || (halo_env && g_force_tile == 0 && g_dma_auto);
+  const ShapeOverride* ov = g_force_tile ? nullptr : find_override(a);
+  const int force = ov ? ov->code : g_force_tile;
+  const bool want = force == 600 || (halo_env && force == 0 && g_dma_auto);
   // (8x8 images, four per tile, are supported but measure no better than the split-K ring: forced only)
-  return want && dtype != DT_F32 && conv_halo_supported(a) && (a.H * a.W >= 256 || g_force_tile == 600);
+  return want && dtype != DT_F32 && conv_halo_supported(a) && (a.H * a.W >= 256 || force == 600);
 }
 
 // the asynchronous LDS-ring kernel (gemm_dma.hip): bf16, one operand pair, enough 128x128 tiles to fill the chip
 int gemm_uses_dma(int dtype, const GemmArgs& a) {
-  if (dtype == DT_F32 || a.A2 || !a.zeros || g_force_tile == 64 || g_force_tile == 128) return 0;
-  if (g_force_tile == 129) return 128;
-  if (g_force_tile == 131) return 130;
-  if (g_force_tile == 133) return 132;
-  if (g_force_tile == 257) return 256;
-  if (g_force_tile == 65) return 64;
-  if (g_force_tile == 67) return 66;
-  if (g_force_tile >= 512 && g_force_tile <= 517) return g_force_tile;
-  if (g_force_tile == 518) return a.gather == GATHER_NONE ? 518 : 515;
+  const ShapeOverride* ov = g_force_tile ? nullptr : find_override(a);
+  const int force = ov ? ov->code : g_force_tile;
+  if (dtype == DT_F32 || a.A2 || !a.zeros || force == 64 || force == 128) return 0;
+  if (force == 129) return 128;
+  if (force == 131) return 130;
+  if (force == 133) return 132;
+  if (force == 257) return 256;
+  if (force == 65) return 64;
+  if (force == 67) return 66;
+  if (force >= 512 && force <= 517) return force;
+  if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
@@ -485,7 +517,9 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // row-bias loads of the epilogue better (43 vs 45 us on 81920x320x320 inside the pass)
   if (t128 >= 400) return (a.K % 64 == 0 && t128 <= 1280) ? 515 : 130;
   if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
-  if (t64 >= 256) return 64;
+  // 64x64 ring, unsplit: also for ~100-250 tiles at K >= 1024 -- inside the pass 11.6 vs 13.8 us (320x1280x1280, ten per iteration) and 11.0 vs
+  // 17.2 us (1280x640x1280) against the register-staged kernel with split-K 5 + reduce (profiles/r02_gemm_override_in_pipeline.txt)
+  if (t64 >= 256 || (t64 >= 96 && a.K >= 1024)) return 64;
   return 0;
 }
 
@@ -506,7 +540,9 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;
+  const ShapeOverride* ov = g_force_splitk ? nullptr : find_override(a);
   if (g_force_splitk) s = g_force_splitk;
+  else if (ov && ov->split) s = ov->split;
   else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
     static const long target = getenv("DPB_SPLITK_TARGET") ? atol(getenv("DPB_SPLITK_TARGET")) : 512;   // tuning switch
     // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
@@ -540,8 +576,11 @@ int gemm_pick_splitk(int dtype, const GemmArgs& a) {
   const long tiles = (long)((a.M + T - 1) / T) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + BK - 1) / BK;
   long s;
+  const ShapeOverride* ov = g_force_splitk ? nullptr : find_override(a);
   if (g_force_splitk) {
     s = g_force_splitk;
+  } else if (ov && ov->split) {
+    s = ov->split;
   } else {
     if (T == 128 || tiles >= 768 || nk < 32) return 1;
     s = (1024 + tiles - 1) / tiles;             // aim at ~4 blocks per CU
@@ -590,7 +629,9 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
       const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
       const int nch = a.Cin / 64;
       long s = 1;
+      const ShapeOverride* ov = g_force_splitk ? nullptr : find_override(a);
       if (g_force_splitk) s = g_force_splitk;
+      else if (ov && ov->split) s = ov->split;
       else if (a.slab) {
         // one resident block per CU: time ~ rounds x (chunks per block + ~2 chunks of prologue / epilogue); measured optimum on
         // the path's layers (profiles/r01_gemm_microbench.txt): 64^2 -> 1, 32^2 -> 2, 16^2 -> 5 splits
