@@ -144,9 +144,15 @@ int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
 /* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
- * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..517: BK=64 rings; 600: halo-tile 3x3 convolution), "gemm_splitk" (n),
- * "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block order per XCD), "gn_deterministic" (0|1: GroupNorm
- * statistics of the two-pass kernels reduced in a fixed order -> bitwise reproducible runs, ~10 % slower; default 0 = atomics). */
+ * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands;
+ * 600: halo-tile 3x3 convolution), "gemm_splitk" (n), "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block
+ * order per XCD), "gn_deterministic" (0|1: GroupNorm statistics of the two-pass kernels reduced in a fixed order -> bitwise reproducible
+ * runs, ~10 % slower; default 0 = atomics), "graph_iterate" (0|1: dpb_pullback_iterate replays a captured hipGraph on a non-default stream;
+ * measured equal to eager launches, default 0).
+ * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
+ * kernel and split count per product shape; DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
+ * DPB_GN_DETERMINISTIC, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L, DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN,
+ * DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants. */
 int dpb_debug_set(const char* key, int value);
 
 #ifdef __cplusplus
