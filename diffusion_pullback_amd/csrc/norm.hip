@@ -526,11 +526,124 @@ __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {   // th
   }
 }
 
+// The same map with LPR lanes per row (64 / LPR rows per wave), for row lengths that are LPR x 3..5 chunks: with one wave per row the
+// 320- / 640-channel rows of the 64 x 64 and 32 x 32 levels keep only 40 of 64 (80 of 128) lanes busy.  Lane l of a row group owns chunks
+// l, l + LPR, ...: the LPR lanes of one load instruction still cover LPR x 16 contiguous bytes of the row.
+template <int LPR>
+__device__ inline float seg_sum(float v) {
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T, int MODE, int LPR, int NI>
+__global__ __launch_bounds__(256) void ln_rows_kernel(LNArgs a, long nrows) {
+  constexpr int CH = TT<T>::CH, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, l = lane % LPR;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < nrows;                 // whole row groups: every lane of a group agrees, the shuffles stay inside the group
+  const long r = live ? row : nrows - 1;
+  long prow = r;
+  if (MODE != MODE_PRIMAL) {
+    long j = r / a.rows_per_sample, ll = r - j * a.rows_per_sample;
+    prow = (j / a.kps) * a.rows_per_sample + ll;
+  }
+  const T* xp = (const T*)a.x + prow * a.C;
+  float x[NI][CH];
+  float v[NI][CH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = l + i * LPR;
+    Vec<T>::load(xp + c * CH, x[i]);
+    if (MODE != MODE_PRIMAL) Vec<T>::load((const T*)a.d + r * a.C + c * CH, v[i]);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s += x[i][e];
+  }
+  const float inv_c = 1.f / a.C;
+  const float mean = seg_sum<LPR>(s) * inv_c;
+  float vs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      x[i][e] -= mean;
+      vs += x[i][e] * x[i][e];
+    }
+  const float rstd = rsqrtf(seg_sum<LPR>(vs) * inv_c + a.eps);
+  T* yp = (T*)a.y + r * a.C;
+  if (MODE == MODE_PRIMAL) {
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = l + i * LPR;
+      float o[CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) o[e] = x[i][e] * rstd * a.gamma[c * CH + e] + a.beta[c * CH + e];
+      Vec<T>::store(yp + c * CH, o);
+    }
+    return;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = l + i * LPR;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      if (MODE == MODE_ADJOINT) v[i][e] *= a.gamma[c * CH + e];
+      x[i][e] *= rstd;                            // xhat
+      s1 += v[i][e];
+      s2 += x[i][e] * v[i][e];
+    }
+  }
+  const float m1 = seg_sum<LPR>(s1) * inv_c, m2 = seg_sum<LPR>(s2) * inv_c;
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = l + i * LPR;
+    float o[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      float w = rstd * (v[i][e] - m1 - x[i][e] * m2);
+      o[e] = (MODE == MODE_TANGENT) ? w * a.gamma[c * CH + e] : w;
+    }
+    if (a.accumulate) {
+      float old[CH];
+      Vec<T>::load(yp + c * CH, old);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) o[e] += old[e];
+    }
+    Vec<T>::store(yp + c * CH, o);
+  }
+}
+
+template <typename T, int MODE, int LPR>
+static bool ln_rows_launch(const LNArgs& a, long nrows, int ni, hipStream_t st) {
+  const dim3 grid((unsigned)((nrows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))));
+  if (ni == 3) hipLaunchKernelGGL((ln_rows_kernel<T, MODE, LPR, 3>), grid, dim3(256), 0, st, a, nrows);
+  else if (ni == 5) hipLaunchKernelGGL((ln_rows_kernel<T, MODE, LPR, 5>), grid, dim3(256), 0, st, a, nrows);
+  else return false;
+  return true;
+}
+
 template <typename T, int MODE>
 static int ln_launch(const LNArgs& a, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
   if (a.C % CH || a.C / CH > 5 * 64) { set_error("layernorm: C=%d unsupported", a.C); return -1; }
   long nrows = (long)((MODE == MODE_PRIMAL) ? a.Bp : a.NT) * a.rows_per_sample;
+  {  // several rows per wave when the row is 8 / 16 / 32 lanes x 3 or 5 chunks (C = 320, 640, 1280; 768: CLIP) -- every lane busy
+    static const int rows_env = getenv("DPB_LN_ROWS") ? atoi(getenv("DPB_LN_ROWS")) : 1;   // tuning switch
+    const int nch = a.C / CH;
+    bool done = false;
+    if (rows_env && nrows > 0) {
+      for (int lpr = 8; lpr <= 32 && !done; lpr *= 2) {
+        if (nch % lpr || (nch / lpr != 3 && nch / lpr != 5)) continue;
+        if (lpr == 8) done = ln_rows_launch<T, MODE, 8>(a, nrows, nch / lpr, st);
+        else if (lpr == 16) done = ln_rows_launch<T, MODE, 16>(a, nrows, nch / lpr, st);
+        else done = ln_rows_launch<T, MODE, 32>(a, nrows, nch / lpr, st);
+      }
+    }
+    if (done) { DPB_CHECK(hipGetLastError()); return 0; }
+  }
   const dim3 grid((unsigned)((nrows + 3) / 4));
   const int need = (a.C / CH + 63) / 64;
   if (need <= 1) hipLaunchKernelGGL((ln_kernel<T, MODE, 1>), grid, dim3(256), 0, st, a, nrows);
