@@ -151,7 +151,7 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
  * measured equal to eager launches, default 0).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
  * kernel and split count per product shape; DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
- * DPB_GN_DETERMINISTIC, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L, DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN,
+ * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L, DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN,
  * DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants. */
 int dpb_debug_set(const char* key, int value);
 
