@@ -364,16 +364,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
       const int m = (int)(mz % p.M), z = (int)(mz / p.M);
       const int n = c * 8;
       const long mn = (long)m * p.N + n;
+      const int z1 = z / p.Z2, z2 = z % p.Z2;
+      T* cp = (T*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2 + (long)m * p.ldc + n;
+      // the epilogue operands are independent of the slabs: fetch them first, so that their latency lies under the slab reads instead of
+      // behind the last sum
+      float bias8[8], rb8[8], r8[8], old8[8];
+      if (p.bias) V8<float>::load(p.bias + n, bias8);
+      if (p.rowbias) V8<T>::load((const T*)p.rowbias + (long)((m / p.rows_per_sample) / p.rowbias_div) * p.N + n, rb8);
+      if (p.R) V8<T>::load((const T*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 + (long)m * p.ldr + n, r8);
+      if (p.accumulate) V8<T>::load(cp, old8);
       float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int s = 0;
-      for (; s + 4 <= p.splitk; s += 4) {          // four slabs in flight per thread; summed in slab order (the order is part of the
-        float t[4][8];                              // bitwise kernel-equivalence contract)
+      for (; s + 8 <= p.splitk; s += 8) {          // eight, then four slabs in flight per thread; summed in slab order (the order is part of
+        float t[8][8];                              // the bitwise kernel-equivalence contract)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) V8<float>::load(p.slab + ((long)(s + u) * Z + z) * MN + mn, t[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[u][e];
+      }
+      if (s + 4 <= p.splitk) {
+        float t[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) V8<float>::load(p.slab + ((long)(s + u) * Z + z) * MN + mn, t[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t[u][e];
+        s += 4;
       }
       for (; s < p.splitk; ++s) {
         float t[8];
@@ -381,30 +400,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += t[e];
       }
-      const int z1 = z / p.Z2, z2 = z % p.Z2;
-      float b8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
       if (p.bias) {
-        V8<float>::load(p.bias + n, b8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
       }
       if (p.rowbias) {
-        V8<T>::load((const T*)p.rowbias + (long)((m / p.rows_per_sample) / p.rowbias_div) * p.N + n, b8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        for (int e = 0; e < 8; ++e) v[e] += rb8[e];
       }
       if (p.R) {
-        V8<T>::load((const T*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 + (long)m * p.ldr + n, b8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        for (int e = 0; e < 8; ++e) v[e] += r8[e];
       }
-      T* cp = (T*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2 + (long)m * p.ldc + n;
       if (p.accumulate) {
-        V8<T>::load(cp, b8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        for (int e = 0; e < 8; ++e) v[e] += old8[e];
       }
       V8<T>::store(cp, v);
     }
@@ -548,9 +560,12 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
     // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
     // profiles/r02_gemm_split_microbench.txt (5120x640: K 1920 / 2560 24 / 32 us unsplit vs 34 / 41 us three-fold, K 5120 52 us two-fold vs
     // 58 unsplit; 1280x3840x1280 25 vs 36 us; 320x10240x1280 18 vs 25 us)
-    if (tiles >= 192) return (tiles < 256 && nk >= 128) ? 2 : 1;
-    s = std::max<long>(1, (target + tiles / 2) / tiles);
-    s = std::min<long>(s, std::max(1, nk / 16));
+    if (tile == 518) return 1;                 // one 8-wave block per CU and >= 160 tiles by construction: never split
+    if (tiles >= 192) s = (tiles < 256 && nk >= 128) ? 2 : 1;
+    else {
+      s = std::max<long>(1, (target + tiles / 2) / tiles);
+      s = std::min<long>(s, std::max(1, nk / 16));
+    }
   } else {
     if (tiles >= 256 || nk < 64) return 1;      // only when CUs would idle and K is long enough to amortise the slabs
     s = (1024 + tiles - 1) / tiles;
@@ -695,7 +710,14 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches) {
   GemmArgs b = a;
   b.fl = dtype == DT_F16;           // 16-bit flavour of the specialised kernels (H16<fl>)
   t_reduce_launched = 0;
+  static const int trace = getenv("DPB_GEMM_TRACE") ? atoi(getenv("DPB_GEMM_TRACE")) : 0;   // debugging: print every product, synchronise after it
+  if (trace) {
+    fprintf(stderr, "gemm M=%d N=%d K=%d Z=%d gather=%d epi=%d lda=%d ldb=%d ldc=%d ldr=%d acc=%d R=%d bias=%d rowbias=%d kind=%d\n", b.M, b.N, b.K, b.Z1 * b.Z2, b.gather,
+            b.epi, b.lda, b.ldb, b.ldc, b.ldr, b.accumulate, b.R != nullptr, b.bias != nullptr, b.rowbias != nullptr, gemm_uses_dma(dtype, b));
+    fflush(stderr);
+  }
   const int r = DPB_DISPATCH_T(dtype, T, launch_t<T>(dtype, b, st));
+  if (trace && hipStreamSynchronize(st) != hipSuccess) fprintf(stderr, "gemm: the launch above failed\n");
   if (launches) *launches = 1 + t_reduce_launched;
   return r;
 }

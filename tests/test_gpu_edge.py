@@ -92,3 +92,40 @@ def test_engine_is_bitwise_reproducible_in_deterministic_mode():
     L.check(L.load().dpb_debug_set(b"gn_deterministic", 0))
     for r in runs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+
+
+def test_graph_replay_of_the_power_iteration_matches_eager_launches():
+    """dpb_debug_set("graph_iterate", 1): dpb_pullback_iterate captures one iteration as a hipGraph (after an eager one) and replays it --
+    the launch sequence of an iteration is fixed for fixed buffers.  Same bits as eager launches in the deterministic mode; capture needs a
+    non-default stream (the legacy default stream cannot be captured: there the option is ignored)."""
+    import torch
+    from diffusion_pullback_amd import PullbackUNet
+    from diffusion_pullback_amd import lib as L
+    from oracle import unet_sd
+    lib = L.load()
+    f = load_golden("pullback_zt_tiny.pt")
+    cfg = unet_sd.SDConfig(**f["cfg"])
+    p = unet_sd.init_params(cfg, seed=f["seed"], gain=f["gain"])
+    net = PullbackUNet("sd", cfg, p, dtype=torch.bfloat16, device="cuda:0", max_batch=1, max_rank=3, verbose=False)
+    eng = net.engine
+    tap = ("mid", 0)
+    V0 = torch.linalg.qr(torch.randn(256, 3, generator=torch.Generator().manual_seed(1)))[0].T.contiguous().cuda()
+    L.check(lib.dpb_debug_set(b"gn_deterministic", 1))
+    try:
+        st = torch.cuda.Stream("cuda:0")
+        out = {}
+        with torch.cuda.stream(st):
+            eng.primal(f["z"], f["t"], f["ctx"], tap)
+            V = V0.clone(); U = torch.empty(3, eng.tap_numel(tap), device="cuda:0"); s = torch.empty(3, device="cuda:0"); conv = torch.empty(1, 2, device="cuda:0")
+            eng._set_stream()
+            for mode in (0, 1, 1):                       # eager, capture + replay, replay of the cached graph
+                L.check(lib.dpb_debug_set(b"graph_iterate", mode))
+                V.copy_(V0)
+                L.check(lib.dpb_pullback_iterate(eng.h, eng.tape.taps[tap], V.data_ptr(), U.data_ptr(), s.data_ptr(), conv.data_ptr(), 3, 6))
+                st.synchronize()
+                out.setdefault(mode, []).append((V.clone(), U.clone(), s.clone()))
+        for got in out[1]:
+            for a, b in zip(out[0][0], got):
+                assert torch.isfinite(a).all() and torch.equal(a, b)
+    finally:
+        L.check(lib.dpb_debug_set(b"graph_iterate", 0)); L.check(lib.dpb_debug_set(b"gn_deterministic", 0))

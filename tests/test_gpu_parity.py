@@ -225,6 +225,36 @@ def test_dma_gemm_bitwise_equals_register_gemm():
         L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
 
 
+def test_large_plain_row_products_on_the_256_tile_match_the_128_tile():
+    """The products the dispatch sends to the 256x256 ring tile at 40 tangents (k = 10 x 4 samples: 10240 rows on the 16x16 level), with the
+    heuristic's own split decision -- a two-fold split of 10240x1280x5120 would need 105 MB of fp32 slabs, more than the 64 MB scratch (this
+    launch once bypassed the capacity clamp and wrote past the slabs) -- equal the 128x128 ring bit for bit (same K16 MFMA order)."""
+    from diffusion_pullback_amd import lib as L
+    from diffusion_pullback_amd.engine import Engine
+    from diffusion_pullback_amd.tape import Tape
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    try:
+        for (H, cin, cout, batch) in [(16, 5120, 1280, 40), (16, 1280, 1280, 40), (8, 1280, 5120, 40)]:
+            p = {"c.weight": torch.randn(cout, cin, 1, 1, generator=g) * 0.02, "c.bias": torch.randn(cout, generator=g)}
+            t = Tape(p, torch.bfloat16, _dev())
+            t.temb_in = t.buf(1, 8, L.BUF_SHARED)
+            t.x = t.buf(H * H, cin)
+            o = t.conv("c", t.x, (H, H), cout, ks=1)
+            t.tap("o", o, cout, H, H)
+            e = Engine(t, 8, False, True, cin, max_batch=batch, max_tangents=batch)
+            x = torch.randn(batch, cin, H, H, generator=g).cuda()
+            outs = []
+            for tile, sk in ((0, 0), (515, 1)):
+                L.check(lib.dpb_debug_set(b"gemm_tile", tile)); L.check(lib.dpb_debug_set(b"gemm_splitk", sk))
+                e.primal(x, 1.0, None, "o")
+                outs.append(e.read("o").clone())
+            assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), (H, cin, cout, batch)
+            del e
+    finally:
+        L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
+
+
 def test_batched_samples_match_single_sample_runs():
     """Several x_t samples advanced together (shared weight stream) give the same bases as one-at-a-time runs."""
     from diffusion_pullback_amd import PullbackUNet
