@@ -2,7 +2,9 @@
 #   gpurun -- 'bash tools/gpu_session.sh TAG [pytest-args...]'      (outputs under gpurun_out/TAG_*)
 TAG=${1:-sess}; shift
 R=$PWD
-python -m pytest tests -m gpu -q -s "$@" > gpurun_out/${TAG}_pytest.log 2>&1; tail -4 gpurun_out/${TAG}_pytest.log
+if [ -z "$SKIP_TESTS" ]; then   # (SKIP_TESTS=1: the suite ran in its own gpurun call -- the whole evidence run does not fit one 40-minute call)
+  timeout 1500 python -m pytest tests -m gpu -q -s "$@" > gpurun_out/${TAG}_pytest.log 2>&1; tail -4 gpurun_out/${TAG}_pytest.log
+fi
 DPB_PROFILE_CSV=gpurun_out/${TAG}_gemm_launches.csv python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-600 gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -o sd15 -- python $R/bench.py --steps 36 --warmup 12 --no-cpu-baseline --no-roofline > /dev/null 2>&1
