@@ -1074,6 +1074,26 @@ int dpb_debug_set(const char* key, int value) {
   return 0;
 }
 
+int dpb_debug_gemm_plan(int dtype, int M, int N, int K, int conv_hw, int conv_cin, int epilogue, int64_t slab_bytes, int* kind, int* tile,
+                        int* splitk) {
+  if (!kind || !tile || !splitk) return fail("null argument");
+  if (dtype != DPB_F32 && dtype != DPB_BF16 && dtype != DPB_F16) return fail("bad dtype %d", dtype);
+  static char dummy[16];                       // the plan only looks at which pointers are set, never through them
+  GemmArgs a;
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+  a.zeros = dummy;
+  if (slab_bytes > 0) { a.slab = (float*)dummy; a.slab_bytes = (size_t)slab_bytes; }
+  a.epi = epilogue;
+  if (conv_hw > 0) {                           // 3x3, stride 1, pad 1 on conv_hw x conv_hw images of conv_cin channels
+    if (conv_cin <= 0 || K != 9 * conv_cin || M % (conv_hw * conv_hw)) return fail("conv plan: K must be 9*cin and M whole images");
+    a.gather = GATHER_CONV; a.H = a.W = a.Ho = a.Wo = conv_hw; a.Cin = conv_cin; a.KS = 3; a.stride = 1; a.pad = 1; a.lda = conv_cin;
+  }
+  const GemmPlan pl = gemm_plan(dtype, a);
+  if (pl.kind < 0) return -1;
+  *kind = pl.kind; *tile = pl.tile; *splitk = pl.splitk;
+  return 0;
+}
+
 int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops, double* gemm_bytes) {
   if (!e) return fail("null engine");
   if (launches) *launches = e->n_launch;

@@ -608,6 +608,51 @@ int gemm_pick_splitk(int dtype, const GemmArgs& a) {
   return (int)std::max<long>(s, 1);
 }
 
+// ---- the launch plan of one product: which kernel, which tile, how many K splits.  A pure host function (dpb_debug_gemm_plan exposes it, so
+// the dispatch rules are testable without a GPU); EVERY path's split count passes the slab-capacity clamp here, in one place.
+enum { PLAN_REG64 = 0, PLAN_REG128 = 1, PLAN_RING = 2, PLAN_HALO = 3 };
+GemmPlan gemm_plan(int dtype, const GemmArgs& a) {
+  GemmPlan pl{PLAN_REG64, 0, 1};
+  long s = 1;
+  if (gemm_uses_halo(dtype, a)) {
+    // 3x3 stride-1 convolutions: halo-tile kernel (gemm_halo.hip), one 256x128 tile per block, K split over 64-channel chunks
+    pl.kind = PLAN_HALO; pl.tile = 600;
+    const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    const int nch = a.Cin / 64;
+    const ShapeOverride* ov = g_force_splitk ? nullptr : find_override(a);
+    if (g_force_splitk) s = g_force_splitk;
+    else if (ov && ov->split) s = ov->split;
+    else if (a.slab) {
+      // one resident block per CU: time ~ rounds x (chunks per block + ~2 chunks of prologue / epilogue); measured optimum on
+      // the path's layers (profiles/r01_gemm_microbench.txt): 64^2 -> 1, 32^2 -> 2, 16^2 -> 5 splits
+      long best = 1L << 60;
+      for (long c = 1; c <= nch; ++c) {
+        const long cost = ((tiles * c + 255) / 256) * ((nch + c - 1) / c + 2);
+        if (cost < best) { best = cost; s = c; }
+      }
+    }
+    s = std::min<long>(s, nch);
+  } else {
+    if (a.epi != EPI_PLAIN && !gemm_epi_supported(dtype, a)) {
+      set_error("gemm: fused epilogue %d requested for a launch no ring kernel with 128-column tiles takes (M=%d N=%d K=%d)", a.epi, a.M, a.N, a.K);
+      pl.kind = -1;
+      return pl;
+    }
+    if (const int dt = gemm_uses_dma(dtype, a)) {
+      pl.kind = PLAN_RING; pl.tile = dt;
+      s = a.epi != EPI_PLAIN ? 1 : gemm_pick_splitk_dma(a, dt);
+    } else {
+      pl.kind = gemm_uses_big_tile(dtype, a) ? PLAN_REG128 : PLAN_REG64;
+      pl.tile = pl.kind == PLAN_REG128 ? 128 : 64;
+      s = gemm_pick_splitk(dtype, a);
+    }
+  }
+  const long per = (long)a.M * a.N * a.Z1 * a.Z2 * 4;          // one fp32 slab
+  if (s > 1 && (!a.slab || s * per > (long)a.slab_bytes)) s = a.slab ? (long)a.slab_bytes / per : 1;
+  pl.splitk = (int)std::max<long>(s, 1);
+  return pl;
+}
+
 template <typename T, int BM, int BN, int KCH>
 static void launch_reg_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
@@ -639,56 +684,14 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     const int force = g_force_order >= 0 ? g_force_order : env_order;
     a.order = force >= 0 ? force : (ub > ua ? 1 : 0);
   }
-  {  // 3x3 stride-1 convolutions: halo-tile kernel (gemm_halo.hip), one 256x128 tile per block, K split over 64-channel chunks
-    if (gemm_uses_halo(dtype, a)) {
-      const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-      const int nch = a.Cin / 64;
-      long s = 1;
-      const ShapeOverride* ov = g_force_splitk ? nullptr : find_override(a);
-      if (g_force_splitk) s = g_force_splitk;
-      else if (ov && ov->split) s = ov->split;
-      else if (a.slab) {
-        // one resident block per CU: time ~ rounds x (chunks per block + ~2 chunks of prologue / epilogue); measured optimum on
-        // the path's layers (profiles/r01_gemm_microbench.txt): 64^2 -> 1, 32^2 -> 2, 16^2 -> 5 splits
-        long best = 1L << 60;
-        for (long c = 1; c <= nch; ++c) {
-          const long cost = ((tiles * c + 255) / 256) * ((nch + c - 1) / c + 2);
-          if (cost < best) { best = cost; s = c; }
-        }
-      }
-      s = std::min<long>(s, nch);
-      const long per = (long)a.M * a.N * 4;
-      if (a.slab && s * per > (long)a.slab_bytes) s = (long)a.slab_bytes / per;
-      a.splitk = (int)std::max<long>(s, 1);
-      if (int r = launch_conv_halo(a, st)) return r;
-      if (a.splitk > 1) {
-        long total = (long)a.M * a.N / 4;
-        unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
-        t_reduce_launched = 1;
-        DPB_CHECK(hipGetLastError());
-      }
-      return 0;
-    }
-  }
-  if (a.epi != EPI_PLAIN && !gemm_epi_supported(dtype, a)) {
-    set_error("gemm: fused epilogue %d requested for a launch no ring kernel with 128-column tiles takes (M=%d N=%d K=%d)", a.epi, a.M, a.N, a.K);
-    return -1;
-  }
-  if (int dt = gemm_uses_dma(dtype, a)) {
-    a.splitk = a.epi != EPI_PLAIN ? 1 : gemm_pick_splitk_dma(a, dt);
-    if (int r = dt >= 512 ? launch_gemm_ring64(a, dt, st) : launch_gemm_dma(a, dt, st)) return r;
-    if (a.splitk > 1) {
-      long total = (long)a.M * a.N * Z / 4;
-      unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
-      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
-      t_reduce_launched = 1;
-      DPB_CHECK(hipGetLastError());
-    }
-    return 0;
-  }
-  a.splitk = gemm_pick_splitk(dtype, a);
-  if (gemm_uses_big_tile(dtype, a)) {
+  const GemmPlan pl = gemm_plan(dtype, a);
+  if (pl.kind < 0) return -1;
+  a.splitk = pl.splitk;
+  if (pl.kind == PLAN_HALO) {
+    if (int r = launch_conv_halo(a, st)) return r;
+  } else if (pl.kind == PLAN_RING) {
+    if (int r = pl.tile >= 512 ? launch_gemm_ring64(a, pl.tile, st) : launch_gemm_dma(a, pl.tile, st)) return r;
+  } else if (pl.kind == PLAN_REG128) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);
     launch_reg_t<T, 128, 128, 4>(a, grid, st);
   } else {

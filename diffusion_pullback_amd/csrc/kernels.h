@@ -43,6 +43,8 @@ struct GemmArgs {
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches = nullptr);   // *launches: kernels enqueued (1, or 2 with splitk_reduce_kernel)
+struct GemmPlan { int kind, tile, splitk; };   // kind: 0 / 1 register-staged 64x64 / 128x128, 2 LDS ring (tile = its code), 3 halo-tile convolution; -1 error
+GemmPlan gemm_plan(int dtype, const GemmArgs& a);   // host-only: the kernel launch_gemm picks, with its K split (clamped to the slab scratch)
 int gemm_uses_big_tile(int dtype, const GemmArgs& a);
 void gemm_debug_set(int tile, int splitk, int kch);
 int gemm_kch(const GemmArgs& a);

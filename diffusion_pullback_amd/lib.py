@@ -71,6 +71,7 @@ SYMBOLS = {
     "dpb_engine_stats": (_I, [_P, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dpb_engine_profile": (_I, [_P, _I]),
     "dpb_debug_set": (_I, [C.c_char_p, _I]),
+    "dpb_debug_gemm_plan": (_I, [_I, _I, _I, _I, _I, _I, _I, _L, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "dpb_engine_profile_dump": (_I, [_P, C.c_char_p]),
     "dpb_engine_profile_read": (_I, [_P, _I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

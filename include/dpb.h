@@ -155,6 +155,14 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
  * DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants. */
 int dpb_debug_set(const char* key, int value);
 
+/* Host-only (no GPU work): the launch plan the GEMM dispatch picks for a product C[M][N] = A[M][K] B[N][K]^T -- plain rows (conv_hw = 0) or
+ * a 3x3 / stride 1 / pad 1 convolution on conv_hw x conv_hw images of conv_cin channels (K = 9 conv_cin) -- with `slab_bytes` of split-K
+ * scratch.  kind: 0 / 1 register-staged 64x64 / 128x128 tile, 2 asynchronous LDS ring (tile = its code, see dpb_debug_set), 3 halo-tile
+ * convolution; epilogue 0 plain, 1 / 2 fused GEGLU tangent / adjoint.  splitk x M x N x 4 bytes never exceeds slab_bytes.  Lets the
+ * dispatch rules be tested on a machine without a GPU (tests/test_host_logic.py). */
+int dpb_debug_gemm_plan(int dtype, int M, int N, int K, int conv_hw, int conv_cin, int epilogue, int64_t slab_bytes, int* kind, int* tile,
+                        int* splitk);
+
 #ifdef __cplusplus
 }
 #endif

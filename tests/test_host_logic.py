@@ -159,3 +159,54 @@ def test_sd_model_id_selects_architecture(tmp_path):
     t = build_sd(tiny21, p21, torch.bfloat16, "cpu", upto=("mid", 0))      # per-block head counts + Linear projections build
     heads = [o["ip"][0] for o in t.ops if o["kind"] == 4]
     assert heads == [1, 1, 2, 2]                                           # down0 self/cross (1 head), mid self/cross (heads[-1] = 2)
+
+
+def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
+    """dpb_debug_gemm_plan (host-only) over the products of the SD-1.5 / SD-2.1 pullback path at k = 1..10 and 1..8 samples advanced together:
+    every plan's split count fits the fp32 slab scratch (a rule once returned before the capacity clamp: 10240 x 1280 x 5120 split two-fold
+    wrote 105 MB of partials into 64 MB), the 256x256 tile is never split and only takes products it tiles with < 7 % padding, fused GEGLU
+    epilogues only go to kernels that implement them, fp32 never leaves the register-staged kernel."""
+    import ctypes as C
+    from diffusion_pullback_amd import lib as L
+    lib = L.load()
+    slab = 64 << 20
+
+    def plan(dtype, M, N, K, hw=0, cin=0, epi=0):
+        k, t, s = C.c_int(), C.c_int(), C.c_int()
+        L.check(lib.dpb_debug_gemm_plan(dtype, M, N, K, hw, cin, epi, slab, C.byref(k), C.byref(t), C.byref(s)))
+        return k.value, t.value, s.value
+
+    chans = (320, 640, 960, 1280, 1920, 2560, 3840, 5120, 10240)
+    n_plans = 0
+    for nt in (1, 3, 5, 10, 20, 40, 80):
+        for hw in (8, 16, 32, 64):
+            M = nt * hw * hw
+            for N in chans:
+                for K in (320, 640, 1280, 2560, 5120, 10240):
+                    for dt in (L.DPB_BF16, L.DPB_F16, L.DPB_F32):
+                        kind, tile, s = plan(dt, M, N, K)
+                        n_plans += 1
+                        assert s >= 1 and s * M * N * 4 <= slab or s == 1, (dt, M, N, K, kind, tile, s)
+                        if dt == L.DPB_F32:
+                            assert kind in (0, 1), (M, N, K, kind, tile)
+                        if tile == 518:
+                            t256 = -(-M // 256) * -(-N // 256)
+                            assert s == 1 and K >= 640 and t256 >= 160 and t256 * 65536 <= 1.07 * M * N, (M, N, K, s)
+            for cin in (320, 640, 1280, 1920, 2560):          # 3x3 convolutions of the ResBlocks
+                for cout in (320, 640, 1280):
+                    kind, tile, s = plan(L.DPB_BF16, M, cout, 9 * cin, hw, cin)
+                    n_plans += 1
+                    assert s >= 1 and (s == 1 or s * M * cout * 4 <= slab), (M, cout, cin, kind, tile, s)
+                    assert kind in (2, 3), (M, cout, cin, kind)           # bf16 convolutions of these sizes: ring or halo-tile kernel
+                    if kind == 3:
+                        assert hw >= 16 and s <= cin // 64
+    assert n_plans > 4000
+    # the launch that overflowed: now the 256x256 tile, unsplit; and the same product forced onto the 128x128 ring keeps within the scratch
+    assert plan(L.DPB_BF16, 10240, 1280, 5120) == (2, 518, 1)
+    # fused GEGLU epilogues: FF-in tangent (N = 2F interleaved) and FF-out adjoint (N = F) of every level go to ring kernels, unsplit
+    for M, F, Cc in ((20480, 1280, 320), (5120, 2560, 640), (1280, 5120, 1280), (40960, 2560, 640), (2560, 5120, 1280)):
+        for epi, N, K in ((1, 2 * F, Cc), (2, F, Cc)):
+            kind, tile, s = plan(L.DPB_BF16, M, N, K, epi=epi)
+            assert kind == 2 and s == 1 and (tile in (128, 130, 132, 256, 518) or 512 <= tile <= 517), (M, N, K, epi, kind, tile, s)
+            if tile == 518:
+                assert N % 256 == 0
