@@ -192,9 +192,10 @@ def main():
         else:
             run_weak(a.warmup, xs)
     if dist and a.warmup > 0:                             # untimed: RCCL sets up its channels on the first all_gather of a size class
-        wz = {i: (torch.zeros(n_h, k, device=dev), torch.zeros(k, device=dev), torch.zeros(k, n_in, device=dev))
-              for i in pdist.shard_indices(world * max(1, S), rank, world)}
-        pdist.gather_bases(wz, world * max(1, S))
+        n_warm_total = a.samples if strong else n_samples * world      # the SAME packed size as the timed gather (a new size class sets up anew)
+        # ... and the same tensor layouts (u is a transposed view: its packing copy is another kernel, loaded lazily on first use)
+        zu, zs, zv = torch.zeros(k, n_h, device=dev).T, torch.zeros(k, device=dev), torch.zeros(k, n_in, device=dev)
+        pdist.gather_bases({i: (zu, zs, zv) for i in pdist.shard_indices(n_warm_total, rank, world)}, n_warm_total)
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -202,7 +203,10 @@ def main():
     t0 = time.perf_counter()
     local_res = run_strong() if strong else run_weak(steps, xs)
     n_total = a.samples if strong else n_samples * world
+    gather_ms = None
     if dist:   # final basis gather: the only collective of the path, ONE packed all_gather (RCCL over xGMI)
+        torch.cuda.synchronize(dev)                       # (splits the timed region into compute | collective for the report; no extra cost:
+        tg = time.perf_counter()                          #  the gather needs the finished bases anyway)
         allres = pdist.gather_bases(local_res, n_total)
     else:
         allres = local_res
@@ -211,6 +215,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    if dist:
+        gather_ms = 1e3 * (time.perf_counter() - tg)
     if dist:
         td = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
@@ -234,7 +240,8 @@ def main():
                    "samples_this_rank": n_samples, "samples_advanced_together": S, "spectrum": "flat" if a.flat_spectrum else "shaped (configs.Spectrum())",
                    "parallelism": (f"{world} ranks (RCCL world_size {world}), sample i on rank i mod {world}, one packed all_gather of (u,s,vT)" if dist
                                    else "single process, no collective"),
-                   "rccl_world_size": world if dist else 0},
+                   "rccl_world_size": world if dist else 0,
+                   "gather_and_barrier_ms": gather_ms},          # part of the timed region: the packed all_gather + the closing barrier (this rank)
         "finite": finite, "s_top": [round(v, 4) for v in s0.cpu().tolist()[:k]],
     }
 
