@@ -7,6 +7,11 @@ iterations.  The only collective is an ``all_gather`` of the final bases (u, s, 
 ``nccl`` backend that is RCCL over xGMI; <= 4 MB per sample, latency-bound, so one flat gather of a
 packed tensor per call (not one per sample, and never a ring all-reduce inside the loop).
 The same code runs under ``gloo`` on CPU tensors (tests/test_dist.py, world_size 2).
+
+Fewer samples than GPUs (the editing CLI works on ONE image): ``k_sharded_power_iteration`` deals the k directions of one
+sample to the ranks instead -- w_i = J^T J v_i is independent per direction -- with one all_gather of W [k, N_in] (<= 655 KB at
+k = 10, SD latents) per iteration in front of the re-orthonormalisation, which every rank repeats on the full W.  Never a ring
+all-reduce inside the loop.
 """
 from __future__ import annotations
 
@@ -74,3 +79,59 @@ def sharded_pullback(compute: Callable[[int], Tuple[torch.Tensor, torch.Tensor, 
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     local = {i: compute(i) for i in shard_indices(n_samples, rank, world)}
     return gather_bases(local, n_samples, group)
+
+
+def k_shard(k: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous direction slice [lo, hi) of rank `rank`: ceil(k / world) per rank, the tail ranks may hold fewer or none."""
+    per = (k + world - 1) // world
+    lo = min(k, rank * per)
+    return lo, min(k, lo + per)
+
+
+def _all_gather_rows(x: torch.Tensor, k: int, group=None) -> torch.Tensor:
+    """x: this rank's rows [hi - lo, n] of a [k, n] matrix split by k_shard -> the full [k, n] on every rank (ONE all_gather of equal,
+    zero-padded pieces; the padding sits at the tail of the flattened result and is cut off)."""
+    if not dist.is_initialized():
+        return x
+    world = dist.get_world_size(group)
+    per = (k + world - 1) // world
+    piece = torch.zeros(per, x.shape[1], dtype=x.dtype, device=x.device)
+    piece[:x.shape[0]] = x
+    out = torch.empty(world * per, x.shape[1], dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, piece, group=group)
+    return out[:k]
+
+
+def k_sharded_power_iteration(jtj: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
+                              orth: Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],
+                              V0: torch.Tensor, n_iters: int, group=None):
+    """Subspace iteration on J^T J for ONE sample with the k directions dealt to the ranks.
+
+    jtj(V_local [m, N_in]) -> (U_local [m, N_h], W_local [m, N_in]) = (J V, J^T J V) for this rank's m >= 1 directions (the engine's
+    jvp + vjp on a primal every rank has run for the same sample); orth(W [k, N_in], V_prev [k, N_in]) -> (V, s, conv) is the
+    re-orthonormalisation (engine.orth).  V0 [k, N_in] is the same on every rank.  Returns (U [k, N_h], s [k], V [k, N_in], conv),
+    identical on every rank: per iteration one all_gather of W, at the end one of U.  (Reference loop: src/utils/utils.py:756-808.)"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    k = V0.shape[0]
+    lo, hi = k_shard(k, rank, world)
+    V = V0
+    U_loc = s = conv = None
+    n_h = None
+    for _ in range(n_iters):
+        if hi > lo:
+            U_loc, W_loc = jtj(V[lo:hi].contiguous())
+            n_h = U_loc.shape[1]
+        else:                                              # more ranks than directions: this rank only takes part in the collectives
+            W_loc = V.new_zeros(0, V.shape[1])
+        W = _all_gather_rows(W_loc, k, group)
+        V, s, conv = orth(W, V)
+    if world > 1:                                          # J V of the last iteration, all directions
+        nh = torch.tensor([n_h or 0], dtype=torch.int64, device=V.device)
+        dist.all_reduce(nh, op=dist.ReduceOp.MAX, group=group)
+        if U_loc is None or hi == lo:
+            U_loc = V.new_zeros(0, int(nh.item()))
+        U = _all_gather_rows(U_loc, k, group)
+    else:
+        U = U_loc
+    return U, s, V, conv

@@ -65,6 +65,9 @@ class PullbackUNet:
             self.engine = Engine(tape, cfg.ch, False, True, cfg.in_channels, max_batch, max_rank)
             self.in_shape = (cfg.in_channels, cfg.resolution, cfg.resolution)
         self.max_rank = max_rank
+        # False: local_encoder_pullback_zt / _xt run all k directions here (default).  None or a torch.distributed group: the directions of the
+        # ONE sample are dealt to that group's ranks (every rank must make the same call; see _pullback and dist.k_sharded_power_iteration)
+        self.k_shard_group = False
 
     # ------------------------------------------------------------------ feature map
     def _tap(self, op, block_idx):
@@ -106,10 +109,22 @@ class PullbackUNet:
         eng.primal(x, _t_float(t), ctx, key)
         U = s = None
         self.last_history = []                                 # per-iteration ||V_prev - V||_2 (what the reference prints, utils.py:804)
+        # One sample on several GPUs (self.k_shard_group set, process group initialised, every rank called with the same inputs): this rank
+        # runs the JVP / VJP of its slice of the k directions, one all_gather of W precedes the re-orthonormalisation (dist.py).  W -- and
+        # with it V, s and the stop decision -- is identical on every rank.
+        import torch.distributed as tdist
+        from . import dist as pdist
+        shard = self.k_shard_group is not False and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(self.k_shard_group) > 1
+        lo, hi = pdist.k_shard(k, tdist.get_rank(self.k_shard_group), tdist.get_world_size(self.k_shard_group)) if shard else (0, k)
         for i in range(max_iter):
             V_prev = V
-            U = torch.cat([eng.jvp(key, vi) for vi in V.chunk(chunks)], dim=0)
-            W = torch.cat([eng.vjp(key, ui) for ui in U.chunk(chunks)], dim=0)
+            if hi > lo:
+                U = torch.cat([eng.jvp(key, vi) for vi in V[lo:hi].chunk(chunks)], dim=0)
+                W = torch.cat([eng.vjp(key, ui) for ui in U.chunk(chunks)], dim=0)
+            else:
+                U, W = V.new_zeros(0, eng.tap_numel(key)), V.new_zeros(0, n_in)
+            if shard:
+                W = pdist._all_gather_rows(W, k, self.k_shard_group)
             V, s, conv = eng.orth(W, V_prev)
             dist, viol = conv.tolist()                                            # the only host sync per iteration
             self.last_history.append(dist)
@@ -122,6 +137,8 @@ class PullbackUNet:
         self.last_iters, self.last_dist = i + 1, dist          # introspection for bench.py's time-to-converged-basis leg
         if self.verbose:
             print("power method runtime ==", time.time() - time_s)
+        if shard:
+            U = pdist._all_gather_rows(U, k, self.k_shard_group)
         dt = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
         return U.T.to(dt), s.to(dt), V.to(dt)
 
@@ -148,6 +165,25 @@ class PullbackUNet:
         if V.shape[0] == pca_rank and b > 1:
             V = V.repeat(b, 1)
         V, U, s, conv = self.engine.iterate(key, V.contiguous().clone(), n_iters)
+        return U.T, s, V, conv
+
+
+    def pullback_k_sharded(self, x, t, ctx, op, block_idx, pca_rank, n_iters, V0, group=None):
+        """ONE sample on several GPUs: the pca_rank directions are dealt to the ranks of `group` (dist.k_sharded_power_iteration); every
+        rank calls this with the same x, t, ctx, V0 and gets the same (u [N_h, k], s [k], vT [k, N_in], conv).  For the case the
+        sample-sharded path cannot use all GPUs (fewer samples than ranks: the editing CLI's single image)."""
+        from . import dist as pdist
+        if x.shape[0] != 1:
+            raise ValueError("pullback_k_sharded works on a single sample")
+        key = self._tap(op, block_idx)
+        eng = self.engine
+        eng.primal(x, _t_float(t), ctx, key)
+        V = V0.reshape(pca_rank, eng.n_in).to(device=self.device, dtype=torch.float32).contiguous()
+
+        def jtj(Vl):
+            U = eng.jvp(key, Vl)
+            return U, eng.vjp(key, U)
+        U, s, V, conv = pdist.k_sharded_power_iteration(jtj, eng.orth, V, n_iters, group)
         return U.T, s, V, conv
 
 

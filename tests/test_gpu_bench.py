@@ -52,6 +52,35 @@ def test_gather_bases_on_nccl_world_size_1():
         dist.destroy_process_group()
 
 
+def test_k_sharded_single_sample_pullback_on_nccl_world_size_1():
+    """PullbackUNet.pullback_k_sharded (one sample, directions dealt to the ranks, one all_gather of W per iteration) on the RCCL backend at
+    world_size 1 equals the fused on-device loop (pullback_fixed); the 2-rank split of the directions is covered on CPU (tests/test_dist.py)."""
+    import torch.distributed as dist
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    from _util import abs_cos, load_golden
+    f = load_golden("pullback_zt_tiny.pt")
+    cfg = unet_sd.SDConfig(**f["cfg"])
+    p = unet_sd.init_params(cfg, seed=f["seed"], gain=f["gain"])
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    net = PullbackUNet("sd", cfg, p, dtype=torch.float32, device="cuda:0", max_batch=1, max_rank=4, verbose=False)
+    V0 = torch.linalg.qr(torch.randn(256, 4, generator=torch.Generator().manual_seed(3)))[0].T.contiguous()
+    u0, s0, V_0, _ = net.pullback_fixed(f["z"], f["t"], f["ctx"], "mid", 0, 4, 5, V0)
+    u0, s0, V_0 = u0.clone(), s0.clone(), V_0.clone()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        u1, s1, V_1, _ = net.pullback_k_sharded(f["z"], f["t"], f["ctx"], "mid", 0, 4, 5, V0)
+        net.k_shard_group = None                                            # the reference-API loop with sharding switched on (world 1: plain loop)
+        u2, s2, V_2 = net.local_encoder_pullback_zt(f["z"], f["t"], f["ctx"], op="mid", block_idx=0, pca_rank=4, min_iter=1, max_iter=5,
+                                                    convergence_threshold=1e-9, V0=V0)
+        net.k_shard_group = False
+    finally:
+        dist.destroy_process_group()
+    assert torch.allclose(s1, s0, rtol=1e-4) and (abs_cos(V_1, V_0) > 0.9999).all() and (abs_cos(u1.T, u0.T) > 0.9999).all()
+    assert torch.allclose(s2.cpu(), s0.cpu(), rtol=1e-4) and (abs_cos(V_2, V_0) > 0.9999).all()
+
+
 def test_bench_under_torchrun_matches_plain_run():
     common = ["--gpus", "1", "--steps", "240", "--warmup", "12", "--workload", "toy", "--k", "3", "--no-cpu-baseline", "--no-roofline"]
     plain = _bench(common)
