@@ -256,7 +256,8 @@ def main():
         tname = "float" if dname == "fp32" else dname.replace("fp16", "f16")
         kinds = {"gemm_kernel<%s,64,64,4>" % tname: eng.profile_read(0), "gemm_kernel<%s,128,128,4>" % tname: eng.profile_read(1),
                  "gemm_dma_kernel<128,128,3> / <256,128,3>": eng.profile_read(2), "gemm_dma_kernel<64,64,4>": eng.profile_read(3),
-                 "gemm_ring64_kernel<128,128,2>": eng.profile_read(4), "conv_halo_kernel": eng.profile_read(5)}
+                 "gemm_ring64_kernel<128,128,2>": eng.profile_read(4), "conv_halo_kernel": eng.profile_read(5),
+                 "gemm_ring64_kernel<256,256,2> (8 waves)": eng.profile_read(6)}
         eng.profile(False)
         dom = max(kinds, key=lambda n: kinds[n][1])                      # dominant = most GPU time
         n_d, ms_d, fl_d = kinds[dom]

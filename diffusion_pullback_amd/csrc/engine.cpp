@@ -130,7 +130,7 @@ int gemm(dpb_engine* e, GemmArgs a) {
   if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl); e->n_launch += nl; return r; }
   dpb_engine::Prof p;
   p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
-  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring, 5: halo-tile 3x3 convolution
+  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile
   p.M = a.M; p.N = a.N; p.K = a.K; p.Z = a.Z1 * a.Z2; p.gather = a.gather;
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));

@@ -139,7 +139,8 @@ int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops,
 /* Measurement aid (bench.py roofline leg, never on in a timed region): bracket every GEMM launch with HIP
  * events on the engine's stream; _read synchronises and sums the launches of one GEMM kernel kind: count, total
  * milliseconds, algorithmic flops.  kind: 0 register-staged 64x64, 1 register-staged 128x128, 2 BK=32 ring 128x128 /
- * 256x128, 3 BK=32 ring 64x64, 4 BK=64 ring (gemm_ring64.hip), 5 halo-tile 3x3 convolution (gemm_halo.hip).  _dump writes one CSV line per recorded launch. */
+ * 256x128, 3 BK=32 ring 64x64, 4 BK=64 ring with 128-column tiles (gemm_ring64.hip), 5 halo-tile 3x3 convolution (gemm_halo.hip), 6 BK=64 ring
+ * with the 256x256 tile.  _dump writes one CSV line per recorded launch. */
 int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);

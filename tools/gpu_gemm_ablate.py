@@ -23,7 +23,7 @@ def run_ab(name, H, cin, cout, ks, batch, tiles=(515,)):
         e.profile(True)
         for _ in range(10):
             e.primal(x, 1.0, None, "o")
-        ms = sum(e.profile_read(kind)[1] for kind in (0, 1, 2, 3, 4, 5)) / 10
+        ms = sum(e.profile_read(kind)[1] for kind in (0, 1, 2, 3, 4, 5, 6)) / 10
         e.profile(False)
         out.append(f"t{tile}:{ms*1e3:6.1f}us")
     L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))

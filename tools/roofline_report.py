@@ -13,7 +13,7 @@ DIR = sys.argv[1] if len(sys.argv) > 1 else "profiles"
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
 ITERS = float(sys.argv[3]) if len(sys.argv) > 3 else 48.0        # tools/gpu_session.sh: 12 warm-up + 36 timed iterations
 PEAK_TF, PEAK_HBM = 2500.0, 8.0                                    # bf16 dense MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
-KIND = {"0": "gemm_kernel", "1": "gemm_kernel", "2": "gemm_dma_kernel", "3": "gemm_dma_kernel", "4": "gemm_ring64_kernel", "5": "conv_halo_kernel"}
+KIND = {"0": "gemm_kernel", "1": "gemm_kernel", "2": "gemm_dma_kernel", "3": "gemm_dma_kernel", "4": "gemm_ring64_kernel", "5": "conv_halo_kernel", "6": "gemm_ring64_kernel"}
 
 
 def family(name):
