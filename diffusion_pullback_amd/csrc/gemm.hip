@@ -528,7 +528,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // -- up to ~1300 tiles; beyond (several samples advanced together: 81920 rows) the BK=32 ring's three blocks per CU hide the residual /
   // row-bias loads of the epilogue better (43 vs 45 us on 81920x320x320 inside the pass)
   if (t128 >= 400) return (a.K % 64 == 0 && t128 <= 1280) ? 515 : 130;
-  if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)    // long K, under-filled: 128x128 ring + split-K (halves operand re-reads vs 64x64)
+  if (a.K >= 2048 && t128 >= 64) return 256;    // long K, under-filled: 256x128 ring + split-K (fewest operand re-reads)
   // 64x64 ring, unsplit: also for ~100-250 tiles at K >= 1024 -- inside the pass 11.6 vs 13.8 us (320x1280x1280, ten per iteration) and 11.0 vs
   // 17.2 us (1280x640x1280) against the register-staged kernel with split-K 5 + reduce (profiles/r02_gemm_override_in_pipeline.txt)
   if (t64 >= 256 || (t64 >= 96 && a.K >= 1024)) return 64;
