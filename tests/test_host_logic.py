@@ -210,3 +210,38 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
             assert kind == 2 and s == 1 and (tile in (128, 130, 132, 256, 518) or 512 <= tile <= 517), (M, N, K, epi, kind, tile, s)
             if tile == 518:
                 assert N % 256 == 0
+
+
+def test_gemm_override_environment_changes_the_plan_of_the_named_shape_only():
+    """DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." (the in-pipeline tuning hook of tools/gpu_gemm_override.py) is read once per process:
+    checked in a child process through dpb_debug_gemm_plan -- the named shape gets the forced kernel and split (still clamped to the slab
+    scratch), every other shape keeps the heuristic's plan."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, json\n"
+        "from diffusion_pullback_amd import lib as L\n"
+        "lib = L.load()\n"
+        "def plan(M, N, K, slab=64 << 20):\n"
+        "    k, t, s = C.c_int(), C.c_int(), C.c_int()\n"
+        "    L.check(lib.dpb_debug_gemm_plan(L.DPB_BF16, M, N, K, 0, 0, 0, slab, C.byref(k), C.byref(t), C.byref(s)))\n"
+        "    return [k.value, t.value, s.value]\n"
+        "print(json.dumps([plan(320, 1280, 1280), plan(1280, 1280, 1280), plan(10240, 1280, 5120), plan(10240, 1280, 5120, 1 << 20)]))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(override):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("DPB_GEMM_OVERRIDE", None)
+        if override:
+            env["DPB_GEMM_OVERRIDE"] = override
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    base = run("")
+    forced = run("320x1280x1280:0=515/4,10240x1280x5120:0=515/2")
+    assert base[0] == [2, 64, 1] and forced[0] == [2, 515, 4]            # the named shape: 64x64 ring unsplit -> BK=64 ring, four-fold
+    assert forced[1] == base[1]                                            # an unnamed shape keeps its plan
+    assert base[2] == [2, 518, 1] and forced[2] == [2, 515, 1]             # 2 x 52 MB of slabs do not fit 64 MB: the forced split is clamped to 1
+    assert forced[3][2] == 1                                               # and with 1 MB of scratch nothing splits
