@@ -43,9 +43,11 @@ __global__ __launch_bounds__(256) void geglu_kernel(GegluArgs a, long nrows) {
         o[e] = av[e] * g1[e];
       }
       Vec<T>::store((T*)a.y + row * a.F + c, o);
-      T* hw = (T*)a.h + prow * 2 * a.F;
-      Vec<T>::store(hw + ca, g1);
-      Vec<T>::store(hw + ca + dg_, g2);
+      if (a.stash) {
+        T* hw = (T*)a.h + prow * 2 * a.F;
+        Vec<T>::store(hw + ca, g1);
+        Vec<T>::store(hw + ca + dg_, g2);
+      }
     } else if (MODE == MODE_TANGENT) {
       const T* dp = (const T*)a.d + row * 2 * a.F;
       float da[CH], dg[CH];

@@ -82,6 +82,7 @@ struct dpb_engine {
   size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
   size_t temb_host_stage = 0;
   int cur_batch = 0;
+  bool fwd_only = false;            // dpb_forward: primal pass that keeps no tangent / adjoint stash (DDIM loop)
   std::vector<char> ginit;
   std::vector<char> skip;           // ops whose work a fused epilogue of another op has done in the current pass
   long n_launch = 0;
@@ -339,6 +340,7 @@ int geglu_run(dpb_engine* e, const Op& op, int mode, int n) {
   if (mode == MODE_PRIMAL) {
     a.Bp = n;
     a.y = e->P(d.out);
+    a.stash = !e->fwd_only;
   } else {
     a.NT = n;
     a.kps = n / e->cur_batch;
@@ -431,14 +433,15 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
   if (int r = launch_softmax_fwd(e->dtype, ws + p.P, (long)B * H, p.Lq, p.Lk, p.Lkp, p.causal, e->stream)) return r;
   // V^T, K^T per head ([d][Lkp], zero padded)
   if (int r = launch_transpose(e->dtype, x.V, ws + p.VT, B, H, (long)p.Lk * x.ldv, p.d, p.Lk, p.d, x.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
-  if (int r = launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
+  if (e->fwd_only) e->n_launch--;   // K^T serves the adjoint only
+  else if (int r = launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r;
   GemmArgs o;   // O = P V
   o.A = ws + p.P; o.lda = p.Lkp; o.sA1 = (long)H * p.Lq * p.Lkp; o.sA2 = (long)p.Lq * p.Lkp;
   o.B = ws + p.VT; o.ldb = p.Lkp; o.sB1 = (long)H * p.d * p.Lkp; o.sB2 = (long)p.d * p.Lkp;
   o.C = x.O; o.ldc = x.ldo; o.sC1 = (long)p.Lq * x.ldo; o.sC2 = p.d;
   o.M = p.Lq; o.N = p.d; o.K = p.Lkp; o.Z1 = B; o.Z2 = H;
   if (int r = gemm(e, o)) return r;
-  if (!p.kv_const) {
+  if (!p.kv_const && !e->fwd_only) {
     e->n_launch += 2;
     if (!p.fused)
       if (int r = launch_transpose(e->dtype, ws + p.P, ws + p.PT, B * H, 1, (long)p.Lq * p.Lkp, 0, p.Lq, p.Lk, p.Lkp, p.Lqp, (long)p.Lk * p.Lqp, e->stream)) return r;
@@ -706,6 +709,8 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
     }
     for (size_t j = 0; j < e->ops.size(); ++j) {
       const dpb_op_desc& d = e->ops[j].d;
+      // the primal GEGLU overwrites its input by the factors (G1, G2) (elementwise.hip): nothing else may read that buffer
+      if (d.kind == DPB_OP_GEGLU && uses[d.in0] != 1) return bad("the input buffer of a GEGLU op must have no other consumer (the primal pass overwrites it in place)", (int)j);
       if (d.kind != DPB_OP_GEGLU || d.ip[1] != 64 || e->ops[j].is_const || getenv("DPB_NO_GEGLU_FUSE")) continue;   // (env: A/B tuning switch)
       const int pi = e->producer[d.in0];
       if (pi >= 0 && uses[d.in0] == 1) {
@@ -823,7 +828,7 @@ int dpb_engine_set_workspace(dpb_engine* e, void* ws, size_t bytes) {
   return 0;
 }
 
-int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf) {
+static int primal_pass(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf) {
   if (!e || !x) return fail("null argument");
   if (!e->ws) return fail("workspace not set (dpb_engine_set_workspace)");
   if (batch < 1 || batch > e->maxB) return fail("batch=%d outside [1,%d]", batch, e->maxB);
@@ -864,6 +869,21 @@ int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* c
   for (int i = 0; i <= last; ++i)
     if (int r = run_op(e, e->ops[i], MODE_PRIMAL, batch)) return r;
   return 0;
+}
+
+int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf) {
+  if (e) e->fwd_only = false;
+  return primal_pass(e, x, batch, t, ctx, upto_buf);
+}
+
+int dpb_forward(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf, int channels, float* out) {
+  if (!e || !out) return fail("null argument");
+  e->fwd_only = true;
+  int r = primal_pass(e, x, batch, t, ctx, upto_buf);
+  e->fwd_only = false;
+  if (!r) r = dpb_read_buffer(e, upto_buf, channels, out);
+  e->cur_batch = 0;                                // no stash was kept: dpb_jvp / dpb_vjp / dpb_pullback_iterate refuse until the next dpb_primal
+  return r;
 }
 
 int dpb_read_buffer(dpb_engine* e, int buf, int channels, float* out) {

@@ -138,6 +138,7 @@ struct GegluArgs {
   void* y = nullptr;           // primal y [.. F] / tangent dy [.. F] / cotangent gh [.. 2F]
   int rows_per_sample = 0, Bp = 1, NT = 0, kps = 1, F = 0;
   int accumulate = 0;
+  int stash = 1;               // primal: 1 = overwrite (a, g) in h by the factors (G1, G2) the tangent / adjoint passes read; 0 = forward only, h untouched
   int il = 0;                  // 0: h = [a | g] halves; 64: a / g interleaved in blocks of 64 columns (FF-in weight rows repacked, tape.py)
 };
 int launch_geglu(int dtype, int mode, const GegluArgs& a, hipStream_t st);

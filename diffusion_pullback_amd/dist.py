@@ -3,7 +3,8 @@
 Each x_t sample's power iteration is independent (the reference itself launches one process per
 sample pinned with --device cuda:N, src/scripts/main_celeba_hf_local_encoder_pullback.sh:2-9), so
 samples are dealt round-robin to ranks, weights are replicated, and nothing is exchanged inside the
-iterations.  The only collective is an ``all_gather`` of the final bases (u, s, vT) -- with the
+iterations.  The only collective is an ``all_gather`` of the final bases (u, s, vT) (plus a 24-byte one of their shapes when the
+caller does not pass them) -- with the
 ``nccl`` backend that is RCCL over xGMI; <= 4 MB per sample, latency-bound, so one flat gather of a
 packed tensor per call (not one per sample, and never a ring all-reduce inside the loop).
 The same code runs under ``gloo`` on CPU tensors (tests/test_dist.py, world_size 2).
@@ -26,25 +27,29 @@ def shard_indices(n_samples: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_samples, world))
 
 
-def gather_bases(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n_samples: int, group=None):
+def gather_bases(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n_samples: int, group=None, shape=None):
     """local: {sample_idx: (u [N_h,k], s [k], vT [k,N_in])} for this rank's samples.
-    Returns the full {idx: (u, s, vT)} on every rank with ONE all_gather of a packed buffer."""
+    Returns the full {idx: (u, s, vT)} on every rank with ONE all_gather of a packed buffer.  ``shape`` = (N_h, k, N_in) when the caller knows
+    it (bench.py, the CLI); without it a second, tiny all_gather of the shapes precedes the payload (a rank that holds no sample cannot know them)."""
     if not dist.is_initialized():          # plain single-process use: nothing to exchange
         return dict(local)
     world = dist.get_world_size(group)      # an initialised group runs the collective even at world_size 1 (RCCL path testable on 1 GPU)
     rank = dist.get_rank(group)
     any_item = next(iter(local.values())) if local else None
-    meta = torch.zeros(3, dtype=torch.int64)
     if any_item is not None:
-        u, s, vT = any_item
-        meta = torch.tensor([u.shape[0], s.shape[0], vT.shape[1]], dtype=torch.int64)
-        dev, dt = u.device, torch.float32
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    metas = [_to_coll(m) for m in metas]
-    dist.all_gather(metas, _to_coll(meta), group=group)
-    n_h, k, n_in = [int(v) for v in max(metas, key=lambda m: int(m.sum())).tolist()]
-    if any_item is None:
+        dev, dt = any_item[0].device, torch.float32
+    else:
         dev, dt = _coll_device(), torch.float32
+    if shape is not None:
+        n_h, k, n_in = (int(v) for v in shape)
+    else:
+        meta = torch.zeros(3, dtype=torch.int64)
+        if any_item is not None:
+            u, s, vT = any_item
+            meta = torch.tensor([u.shape[0], s.shape[0], vT.shape[1]], dtype=torch.int64)
+        metas = [_to_coll(torch.zeros_like(meta)) for _ in range(world)]
+        dist.all_gather(metas, _to_coll(meta), group=group)
+        n_h, k, n_in = [int(v) for v in max(metas, key=lambda m: int(m.sum())).tolist()]
     per = (n_samples + world - 1) // world                  # slots per rank
     stride = n_h * k + k + k * n_in
     buf = torch.zeros(per * stride, dtype=dt, device=dev)

@@ -86,29 +86,33 @@ class Engine:
         c, h, w = self.tape.tap_shape[self.tape.taps[tap]]
         return c * h * w
 
+    def _inputs(self, x: torch.Tensor, ctx: Optional[torch.Tensor]):
+        x = _f32(x, self.device)
+        b = x.shape[0]
+        if x[0].numel() != self.n_in:
+            raise L.DpbError(f"input has {x[0].numel()} elements per sample, network expects {self.n_in}")
+        cbuf = getattr(self.tape, "ctx", -1)
+        if cbuf >= 0:
+            if ctx is None:
+                raise L.DpbError("this network needs encoder_hidden_states (ctx)")
+            rows, cpad, _ = self.tape.buffers[cbuf]
+            width = self.tape.valid[cbuf] or cpad
+            if ctx.dim() != 3 or ctx.shape[1] != rows or ctx.shape[2] != width or ctx.shape[0] not in (1, b):
+                raise L.DpbError(f"encoder_hidden_states has shape {tuple(ctx.shape)}, the engine was built for [{b} or 1, {rows}, {width}] "
+                                 "(token count and width are fixed at engine build time: SDConfig.ctx_len / cross_dim)")
+            ctx = _f32(ctx, self.device)
+            if ctx.shape[0] != b:
+                ctx = ctx.expand(b, -1, -1).contiguous()
+        else:
+            ctx = None
+        return x, b, ctx
+
     def primal(self, x: torch.Tensor, t: float, ctx: Optional[torch.Tensor], tap) -> None:
         """x [B,C,H,W]; ctx [B,L,D] or None.  Keeps the activations resident for jvp/vjp."""
         buf = self.tape.taps[tap]
         with torch.cuda.device(self.device):
             self._set_stream()
-            x = _f32(x, self.device)
-            b = x.shape[0]
-            if x[0].numel() != self.n_in:
-                raise L.DpbError(f"input has {x[0].numel()} elements per sample, network expects {self.n_in}")
-            cbuf = getattr(self.tape, "ctx", -1)
-            if cbuf >= 0:
-                if ctx is None:
-                    raise L.DpbError("this network needs encoder_hidden_states (ctx)")
-                rows, cpad, _ = self.tape.buffers[cbuf]
-                width = self.tape.valid[cbuf] or cpad
-                if ctx.dim() != 3 or ctx.shape[1] != rows or ctx.shape[2] != width or ctx.shape[0] not in (1, b):
-                    raise L.DpbError(f"encoder_hidden_states has shape {tuple(ctx.shape)}, the engine was built for [{b} or 1, {rows}, {width}] "
-                                     "(token count and width are fixed at engine build time: SDConfig.ctx_len / cross_dim)")
-                ctx = _f32(ctx, self.device)
-                if ctx.shape[0] != b:
-                    ctx = ctx.expand(b, -1, -1).contiguous()
-            else:
-                ctx = None
+            x, b, ctx = self._inputs(x, ctx)
             L.check(self.lib.dpb_primal(self.h, _ptr(x), b, float(t), _ptr(ctx), buf))
             self.batch = b
 
@@ -122,8 +126,17 @@ class Engine:
         return out
 
     def forward(self, x, t, ctx=None, tap="eps") -> torch.Tensor:
-        self.primal(x, t, ctx, tap)
-        return self.read(tap)
+        """Forward only (dpb_forward): the U-Net calls of the DDIM / guidance loop and get_h.  Keeps no tangent / adjoint stash,
+        so jvp / vjp / iterate need a primal() first (the engine refuses otherwise)."""
+        buf = self.tape.taps[tap]
+        c, h, w = self.tape.tap_shape[buf]
+        with torch.cuda.device(self.device):
+            self._set_stream()
+            x, b, ctx = self._inputs(x, ctx)
+            out = torch.empty(b, c, h, w, dtype=torch.float32, device=self.device)
+            L.check(self.lib.dpb_forward(self.h, _ptr(x), b, float(t), _ptr(ctx), buf, c, _ptr(out)))
+            self.batch = 0
+        return out
 
     def jvp(self, tap, V: torch.Tensor) -> torch.Tensor:
         """V [nt, N_in] (NCHW-flattened) -> U [nt, N_h]"""

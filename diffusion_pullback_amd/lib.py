@@ -60,6 +60,7 @@ SYMBOLS = {
     "dpb_engine_workspace_bytes": (C.c_size_t, [_P]),
     "dpb_engine_set_workspace": (_I, [_P, _P, C.c_size_t]),
     "dpb_primal": (_I, [_P, _P, _I, _F, _P, _I]),
+    "dpb_forward": (_I, [_P, _P, _I, _F, _P, _I, _I, _P]),
     "dpb_read_buffer": (_I, [_P, _I, _I, _P]),
     "dpb_jvp": (_I, [_P, _I, _P, _I, _P]),
     "dpb_vjp": (_I, [_P, _I, _P, _I, _P]),
@@ -103,6 +104,24 @@ def _built_hash() -> str:
         return ""
 
 
+def _needs_build() -> bool:
+    """Stale or missing binary?  A prebuilt libdpb.so WITHOUT a stamp that is newer than every source is trusted (and stamped)."""
+    want = _source_hash()
+    if want == _built_hash():
+        return False
+    if os.path.exists(LIB_PATH) and not os.path.exists(STAMP_PATH):
+        srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp")) \
+            + [os.path.join(CSRC, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "dpb.h")]
+        if all(os.path.getmtime(f) <= os.path.getmtime(LIB_PATH) for f in srcs if os.path.exists(f)):
+            try:
+                with open(STAMP_PATH, "w") as fh:
+                    fh.write(want)
+            except OSError:
+                pass
+            return False
+    return True
+
+
 def build(force: bool = False) -> str:
     """Compile libdpb.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
@@ -110,9 +129,9 @@ def build(force: bool = False) -> str:
     r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
     if r.returncode != 0:
         raise DpbError("hipcc build of libdpb.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
-    with open(STAMP_PATH, "w") as fh:
+    with open(os.path.join(_HERE, "libdpb.so.srchash"), "w") as fh:     # make always links the in-tree libdpb.so: stamp that one, wherever DPB_LIB points
         fh.write(_source_hash())
-    return LIB_PATH
+    return os.path.join(_HERE, "libdpb.so")
 
 
 def load():
@@ -120,18 +139,22 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.environ.get("DPB_LIB") and os.path.exists(HIPCC) and os.path.isdir(CSRC) and os.access(_HERE, os.W_OK) and _source_hash() != _built_hash():
+    if not os.environ.get("DPB_LIB") and os.path.exists(HIPCC) and os.path.isdir(CSRC) and os.access(_HERE, os.W_OK) and _needs_build():
         # the sources changed since libdpb.so was linked (or it was never built): rebuild in-tree, incrementally -- an edited
         # .hip / dpb.h never runs against a stale binary, and never against a CPU substitute.  The stamp is a content hash, not
-        # mtimes, so a copied tree (gpurun snapshot) with a matching .so does not rebuild.  One builder when several ranks
-        # start together; the lock lives outside the package.
+        # mtimes, so a copied tree (gpurun snapshot) with a matching .so does not rebuild.  One builder when several ranks (or several
+        # hosts sharing the checkout) start together: the lock file lives next to libdpb.so, in tmp only if that directory refuses.
         import fcntl
         import tempfile
-        lock = os.path.join(tempfile.gettempdir(), "dpb-build-%s.lock" % hashlib.sha1(_HERE.encode()).hexdigest()[:12])
-        with open(lock, "w") as lk:
+        lock = os.path.join(_HERE, ".build.lock")
+        try:
+            lk = open(lock, "w")
+        except OSError:
+            lk = open(os.path.join(tempfile.gettempdir(), "dpb-build-%s.lock" % hashlib.sha1(_HERE.encode()).hexdigest()[:12]), "w")
+        with lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
             try:
-                if _source_hash() != _built_hash():
+                if _needs_build():
                     build()
             finally:
                 fcntl.flock(lk, fcntl.LOCK_UN)

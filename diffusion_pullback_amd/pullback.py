@@ -101,20 +101,27 @@ class PullbackUNet:
         key = self._tap(op, block_idx)
         eng = self.engine
         n_in = eng.n_in
-        if V0 is None:
-            q, _ = torch.linalg.qr(torch.randn(n_in, k, dtype=torch.float))     # utils.py:750-753 (CPU generator)
-            V0 = q.T
-        V = V0.reshape(k, n_in).to(device=self.device, dtype=torch.float32).contiguous()
-        time_s = time.time()
-        eng.primal(x, _t_float(t), ctx, key)
-        U = s = None
-        self.last_history = []                                 # per-iteration ||V_prev - V||_2 (what the reference prints, utils.py:804)
         # One sample on several GPUs (self.k_shard_group set, process group initialised, every rank called with the same inputs): this rank
         # runs the JVP / VJP of its slice of the k directions, one all_gather of W precedes the re-orthonormalisation (dist.py).  W -- and
         # with it V, s and the stop decision -- is identical on every rank.
         import torch.distributed as tdist
         from . import dist as pdist
         shard = self.k_shard_group is not False and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(self.k_shard_group) > 1
+        drawn = V0 is None
+        if drawn:
+            q, _ = torch.linalg.qr(torch.randn(n_in, k, dtype=torch.float))     # utils.py:750-753 (CPU generator)
+            V0 = q.T
+        V = V0.reshape(k, n_in).to(device=self.device, dtype=torch.float32).contiguous()
+        if shard and drawn:
+            # every rank drew from its OWN CPU generator: the ranks must start from one V0, or the row signs orth() aligns to V_prev -- and with
+            # them the gathered u_i = +-J v_i -- are rank-specific.  Rank 0 of the group decides.
+            Vc = V if tdist.get_backend(self.k_shard_group) == "nccl" else V.cpu()
+            tdist.broadcast(Vc, src=tdist.get_global_rank(self.k_shard_group, 0) if self.k_shard_group is not None else 0, group=self.k_shard_group)
+            V = Vc.to(self.device)
+        time_s = time.time()
+        eng.primal(x, _t_float(t), ctx, key)
+        U = s = None
+        self.last_history = []                                 # per-iteration ||V_prev - V||_2 (what the reference prints, utils.py:804)
         lo, hi = pdist.k_shard(k, tdist.get_rank(self.k_shard_group), tdist.get_world_size(self.k_shard_group)) if shard else (0, k)
         for i in range(max_iter):
             V_prev = V

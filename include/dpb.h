@@ -35,7 +35,10 @@ enum {
   DPB_OP_GROUPNORM = 2, /* GroupNorm(G, eps) (+SiLU)                                                   */
   DPB_OP_LAYERNORM = 3, /* LayerNorm over channels                                                     */
   DPB_OP_ATTENTION = 4, /* multi-head softmax(q k^T d^-1/2) v ; in0=q in1=k in2=v                      */
-  DPB_OP_GEGLU = 5,     /* [rows][2F] -> [rows][F] : a * gelu_erf(g)                                   */
+  DPB_OP_GEGLU = 5,     /* [rows][2F] -> [rows][F] : a * gelu_erf(g).  dpb_primal OVERWRITES the input buffer
+                           by the factors (gelu(g), a*gelu'(g)) its tangent / adjoint passes read: the input must
+                           have no other consumer (checked at create) and is not a meaningful tap afterwards;
+                           dpb_forward leaves it untouched                                              */
   DPB_OP_SILU = 6,      /* elementwise x*sigmoid(x); ip[0] = 1: quick-GELU x*sigmoid(1.702x), 2: erf GELU (primal only) */
   DPB_OP_CONCAT = 7     /* channel concat of in0, in1                                                  */
 };
@@ -100,6 +103,10 @@ int dpb_engine_set_workspace(dpb_engine* e, void* ws, size_t bytes);
  * ctx: fp32 [batch][ctx_len][ctx_dim] or NULL.
  * Replaces: unet.get_h(...) / unet(x, t, encoder_hidden_states) (utils.py:438-527; edit.py:454-458). */
 int dpb_primal(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf);
+/* Forward only (the U-Net calls of the DDIM / guidance loop, edit.py:454-458, :484-502): the same pass without the tangent / adjoint
+ * stash (no K^T / Q^T / P^T copies, GEGLU inputs left untouched), result copied to `out` as fp32 NCHW [batch][channels][rows(upto_buf)].
+ * Invalidates the engine's primal state: dpb_jvp / dpb_vjp / dpb_pullback_iterate fail until the next dpb_primal. */
+int dpb_forward(dpb_engine* e, const float* x, int batch, float t, const float* ctx, int upto_buf, int channels, float* out);
 /* Copy a primal activation out as fp32 NCHW [batch][channels][rows] (first `channels` channels). */
 int dpb_read_buffer(dpb_engine* e, int buf, int channels, float* out);
 

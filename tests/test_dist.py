@@ -173,3 +173,33 @@ def test_reference_api_loop_with_k_sharding_matches_unsharded_on_two_ranks():
         for out in res[True] + res[False]:
             assert out[4] == ref[4]
             assert all(torch.allclose(torch.tensor(a), torch.tensor(b), rtol=1e-4, atol=1e-4) for a, b in zip(out[1:4], ref[1:4])), (k, out[0])
+
+
+def _pullback_v0_worker(rank, world, port, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffusion_pullback_amd.pullback import PullbackUNet
+    net = object.__new__(PullbackUNet)
+    net.engine, net.device, net.max_rank, net.verbose, net.k_shard_group = _FakeEngine(), torch.device("cpu"), 8, False, None
+    net._tap = lambda op, idx: "mid"
+    torch.manual_seed(1000 + 17 * rank)                     # the ranks are NOT seeded alike: their own V0 draws differ
+    u, s, vT = net._pullback(torch.zeros(1, 1), 1.0, None, "mid", 0, k, 1, 2, 5, 1e-30, None)
+    q.put((rank, u.tolist(), s.tolist(), vT.tolist()))
+    dist.destroy_process_group()
+
+
+def test_k_sharded_loop_with_drawn_v0_is_identical_on_differently_seeded_ranks():
+    """with k_shard_group set and V0=None every rank drew its own V0; rank 0's draw is broadcast now, so (u, s, vT) agree on
+    all ranks and u stays sign-consistent with vT (u_i = J v_i of the previous iterate, checked through the converged basis)."""
+    k = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_pullback_v0_worker, args=(r, 2, port, k, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=120) for _ in ps], key=lambda o: o[0])
+    [p.join(timeout=60) for p in ps]
+    (_, u0, s0, v0), (_, u1, s1, v1) = out
+    for a, b in ((u0, u1), (s0, s1), (v0, v1)):
+        assert torch.equal(torch.tensor(a), torch.tensor(b))
