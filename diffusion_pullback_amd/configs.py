@@ -155,12 +155,24 @@ class Spectrum:
     decay: float = 0.8
     amp: float = 400.0
     q_scale: float = 0.1
+    # SD only: further transformer blocks (parameter prefixes such as "down_blocks.1.attentions.1") whose self-attention is shaped the same way.
+    # The mid-block shaping is not in the prefix of a ('down', i) tap, so those taps keep the flat spectrum unless the LAST self-attention inside
+    # their own prefix is shaped too: Spectrum.for_tap(op, idx).  Default () = the headline weights of rounds 2+ (bench.py, the goldens).
+    also: Tuple[str, ...] = ()
+
+    @staticmethod
+    def for_tap(op: str, idx: int, **kw) -> "Spectrum":
+        """Shaping that separates the top singular values AT tap (op, idx) of SD-v1.x/2.x: mid block + the last self-attention of the tap's prefix."""
+        last = {("down", 0): "down_blocks.0.attentions.1", ("down", 1): "down_blocks.1.attentions.1", ("down", 2): "down_blocks.2.attentions.1",
+                ("down", 3): "down_blocks.2.attentions.1", ("up", 1): "up_blocks.1.attentions.2", ("up", 2): "up_blocks.2.attentions.2",
+                ("up", 3): "up_blocks.3.attentions.2"}.get((op, idx))
+        return Spectrum(also=(last,) if last else (), **kw)
 
 
-def _shape_spectrum(p: Params, w_out: str, w_q: str, sp: Spectrum, seed: int) -> None:
+def _shape_spectrum(p: Params, w_out: str, w_q: str, sp: Spectrum, seed: int, salt: int = 0) -> None:
     if w_out not in p:                       # prefix-restricted parameter sets that stop before the mid block
         return
-    g = torch.Generator().manual_seed(seed + 7919)           # own stream: every other parameter keeps its unshaped bits
+    g = torch.Generator().manual_seed(seed + 7919 + 104729 * salt)   # own stream: every other parameter keeps its unshaped bits
     w = p[w_out]
     c = w.shape[0]
     r = min(sp.rank, c)
@@ -274,6 +286,9 @@ def sd_init_params(cfg: SDConfig, seed: int = 0, gain: float = 1.0, dtype=torch.
     if spectrum is not None:
         tb = "mid_block.attentions.0.transformer_blocks.0.attn1."
         _shape_spectrum(p, tb + "to_out.0.weight", tb + "to_q.weight", spectrum, seed)
+        for n, pre in enumerate(spectrum.also):
+            tb = pre + ".transformer_blocks.0.attn1."
+            _shape_spectrum(p, tb + "to_out.0.weight", tb + "to_q.weight", spectrum, seed, salt=n + 1)
     return p
 
 

@@ -79,6 +79,7 @@ struct dpb_engine {
   // arena offsets
   size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0, gnpart = 0, gnpart_bytes = 0, gnticket = 0;
   size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20, zeros = 0;
+  size_t orth_stride = 0;                  // re-orthonormalisation scratch per sample of the batch
   size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
   size_t temb_host_stage = 0;
   int cur_batch = 0;
@@ -524,10 +525,10 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   // first-write / accumulate flags, read up front: q, k, v may be windows of ONE buffer (fused QKV)
   const int accQ = e->ginit[d.in0], accK = p.kv_const ? 0 : e->ginit[d.in1], accV = p.kv_const ? 0 : e->ginit[d.in2];
   if (p.fused) {
-    e->n_launch += 2;
+    e->n_launch += 2 + (p.d == 40 && kps >= 4);   // (+ the row-dot kernel of the shared-P key-major adjoint)
     FusedAttnArgs f;
     fill_fused(e, p, x, f, kps, scale);
-    f.gO = gO; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V;
+    f.gO = gO; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V; f.Drow = Dv;
     f.accQ = accQ; f.accK = accK; f.accV = accV;
     e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;
     if (int r = launch_attn_adj_fused(f, nt, e->stream)) return r;
@@ -794,7 +795,8 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   const size_t nio = (size_t)std::max(e->maxB, e->maxT) * maxrc * sizeof(float);
   e->io_in = take(nio);
   e->io_out = take(nio);
-  e->orth = take(sizeof(double) * (3 * 56 * 56 + 2) * (size_t)e->maxB);
+  e->orth_stride = align_up(orth_scratch_bytes(56, (long)e->bufs[e->x_buf].rows * e->x_channels));
+  e->orth = take(e->orth_stride * (size_t)e->maxB);
   e->slab = take(e->slab_bytes);
   e->zeros = take(256);
   const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
@@ -863,7 +865,7 @@ static int primal_pass(dpb_engine* e, const float* x, int batch, float t, const 
     e->n_launch++;
     if (int r = launch_nchw_to_nhwc(e->dtype, stage, e->P(e->temb_buf), 1, (int)emb.size(), 1, (int)emb.size(), e->stream)) return r;
   }
-  if (e->pstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));   // atomic statistics path accumulates
+  if (e->pstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));   // atomic statistics path accumulates
   e->cur_batch = batch;
   const int last = e->producer[upto_buf];
   for (int i = 0; i <= last; ++i)
@@ -902,7 +904,7 @@ int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
   const Buf& bx = e->bufs[e->x_buf];
   e->n_launch++;
   if (int r = launch_nchw_to_nhwc(e->dtype, V, e->T(e->x_buf), nt, e->x_channels, bx.rows, bx.C, e->stream)) return r;
-  if (e->tstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
+  if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));   // atomic statistics accumulate
   const int last = e->producer[tap];
   std::fill(e->skip.begin(), e->skip.end(), 0);
   for (int i = 0; i <= last; ++i) {
@@ -924,7 +926,7 @@ int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   e->n_launch++;
   if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
   e->ginit[tap] = 1;
-  if (e->tstats_bytes) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
+  if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
   for (int i = e->producer[tap]; i >= 0; --i) {
     const Op& op = e->ops[i];
     if (op.is_const || !e->ginit[op.d.out]) continue;
@@ -940,8 +942,11 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
   if (!W || !Vprev || !V || !s || !conv || !scratch) return fail("null argument");
   OrthArgs a;
   a.W = W; a.Vprev = Vprev; a.V = V; a.s = s; a.conv = conv; a.scratch = (double*)scratch; a.k = k; a.N = N;
+  a.scratch_bytes = orth_scratch_bytes(k, N);      // the caller's contract (include/dpb.h)
   return launch_orth(a, (hipStream_t)stream);
 }
+
+size_t dpb_orth_scratch_bytes(int k, int64_t N) { return (k < 1 || k > 56 || N < 1) ? 0 : orth_scratch_bytes(k, N); }
 
 static int g_graph_iterate = 0;      // dpb_debug_set("graph_iterate", 1): replay the power iteration as a captured hipGraph (measurement option)
 
@@ -962,9 +967,9 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
     for (int b = 0; b < B; ++b)                     // independent k x N re-orthonormalisation per sample
       if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, Vn + (long)b * k * N, s + b * k, conv + 2 * b,
-                           e->ws + e->orth + (size_t)b * sizeof(double) * (3 * 56 * 56 + 2), k, N, e->stream)) return r;
+                           e->ws + e->orth + (size_t)b * e->orth_stride, k, N, e->stream)) return r;
     DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * nt * N, hipMemcpyDeviceToDevice, e->stream));
-    launches += 5 * B + 1;
+    launches += 4 * B + 1;
     return 0;
   };
   int it = 0;
@@ -1089,6 +1094,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_order")) { gemm_debug_order(value); return 0; }
   else if (!strcmp(key, "gn_deterministic")) { gn_debug_deterministic(value); return 0; }
   else if (!strcmp(key, "graph_iterate")) { g_graph_iterate = value; return 0; }
+  else if (!strcmp(key, "attn_shared")) { attn_debug_shared(value); return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

@@ -73,7 +73,8 @@ struct GNArgs {
   float* part = nullptr;          // per-block partial sums [n][blocks][G][2] (scratch shared by every GroupNorm launch of the stream)
   size_t part_bytes = 0;
   int* ticket = nullptr;          // [n] arrival counters, zero between launches
-  int det = 0;                    // 1: bitwise reproducible statistics (ordered reduction); 0: atomics (default, fastest)
+  int det = 1;                    // 1 (default): bitwise reproducible statistics (fixed-order reductions); 0: atomics (round-1 path, A/B only)
+  int red = 0;                    // set by launch_groupnorm: the apply pass adds the statistics launch's per-block partials itself
   int Bp = 1, NT = 0, kps = 1;    // tangent j belongs to primal sample j / kps
   int HW = 0, C = 0, G = 32;
   float eps = 1e-5f;
@@ -108,6 +109,7 @@ int launch_transpose(int dtype, const void* in, void* out, int Z1, int Z2, long 
 struct FusedAttnArgs {
   const void *Q = nullptr, *K = nullptr, *V = nullptr, *O = nullptr, *KT = nullptr, *VT = nullptr, *QT = nullptr;
   const float* stats = nullptr;
+  float* Drow = nullptr;                             // scratch [nt][H][L] floats for the shared-P key-major adjoint (row dots gO . O)
   const void *dQ = nullptr, *dK = nullptr, *dV = nullptr, *dVT = nullptr; void* dO = nullptr;
   const void *gO = nullptr, *gOT = nullptr; void *gQ = nullptr, *gK = nullptr, *gV = nullptr;
   int accQ = 0, accK = 0, accV = 0;
@@ -116,6 +118,7 @@ struct FusedAttnArgs {
   float scale = 1.f;
 };
 int fused_attention_supported(int dtype, int d, int L, int kv_const);
+void attn_debug_shared(int bits);   // bit 0: shared-P tangent kernel, bit 1: shared-P key-major adjoint (d = 40 layers); default 3
 // constant-K/V (cross) attention tangent / adjoint in one launch (attn_fused.hip): Y = c_out [P o (c_in X A^T - delta)] B
 struct CrossAttnArgs {
   const void *Q = nullptr, *K = nullptr, *V = nullptr;   // primal q [B][L][C]; k, v [B][Lk][Ck] (column windows allowed)
@@ -164,10 +167,12 @@ struct OrthArgs {
   float* V = nullptr;            // [k][N]  right singular vectors of W, rows, descending
   float* s = nullptr;            // [k]     sqrt(singular values of W)   (reference: s.sqrt())
   float* conv = nullptr;         // [2]     {||V - Vprev||_2, max(|V-Vprev| - 1e-5|V|)}
-  double* scratch = nullptr;     // >= 3*k*k + 2*k + 4 doubles
+  double* scratch = nullptr;     // >= orth_scratch_bytes(k, N)
+  size_t scratch_bytes = 0;
   int k = 0; long N = 0;
 };
 int launch_orth(const OrthArgs& a, hipStream_t st);
+size_t orth_scratch_bytes(int k, long N);
 
 // ---------------------------------------------------------------- DDIM
 // x_next = sqrt(a_next) * (x - e*sqrt(1-a_t))/sqrt(a_t) + sqrt(1-a_next) * e      (fp32, elementwise)

@@ -2,10 +2,12 @@
 //
 // HBM-bound kernels.  Every thread owns a fixed 16-byte channel chunk (coalesced rows, per-channel
 // constants loaded once) and walks pixels.  GroupNorm: pass 1 accumulates per-(sample,group) sums, pass 2 applies.
-// Two statistics paths for the two-pass kernels: the default adds block partials with LDS float atomics + one fp64 global atomic per group
-// per block (fastest; the order of the adds varies from run to run); GNArgs::det = 1 (dpb_debug_set("gn_deterministic", 1)) reduces a
-// block's per-channel partials through LDS in a fixed order, publishes one partial per group with write-through stores, and the block
-// that arrives last at a ticket counter adds all partials in block order in fp64 -- bitwise reproducible runs, ~10 % slower end to end.
+// Statistics of the two-pass kernels are bitwise reproducible by default (GNArgs::det = 1): the statistics launch reduces a block's
+// per-channel partials through LDS in a fixed order and stores ONE partial per (block, group) with plain stores; the APPLY launch (a kernel
+// boundary later, so the partials are visible without fences, tickets or atomics) has every block add the partials of its sample / tangent
+// in block order (fp64, 4 fixed segments + a fixed 4-term tail) before it starts -- 32 L2-resident loads per thread.  No run-time-ordered
+// floating-point addition anywhere.  det = 0 (dpb_debug_set("gn_deterministic", 0), A/B only) is the round-1 path: LDS float atomics + one
+// fp64 global atomic per group per block, whose order varies from run to run (sigma_1 = 459.527 / 459.501 / 459.533 across identical runs).
 // Feature maps whose per-sample group window fits a block's registers use the ONE-launch kernel below (deterministic by construction).
 // The tangent and adjoint share one algebraic form:
 //     out = rstd * (v - mean(v) - xhat * mean(xhat * v))
@@ -15,7 +17,7 @@
 
 namespace dpb {
 
-static int g_gn_det = getenv("DPB_GN_DETERMINISTIC") ? atoi(getenv("DPB_GN_DETERMINISTIC")) : 0;
+static int g_gn_det = getenv("DPB_GN_DETERMINISTIC") ? atoi(getenv("DPB_GN_DETERMINISTIC")) : 1;
 void gn_debug_deterministic(int on) { g_gn_det = on; }
 int gn_deterministic() { return g_gn_det; }
 
@@ -23,8 +25,8 @@ template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
   constexpr int CH = TT<T>::CH;
   extern __shared__ float lch[];    // STATS, deterministic path: per-channel partial sums [rpi][C][2] (dynamic: rpi * C * 8 bytes)
-  __shared__ float lsum[2 * 256];   // STATS, atomic path: [G][2]
-  __shared__ int s_last;
+  __shared__ float lsum[2 * 256];   // STATS, atomic path: [G][2]; apply pass, deterministic path: the reduced statistics [G][2]
+  __shared__ double lseg[4][2 * 256];   // apply pass, deterministic path: 4 block-range segment sums per statistic
   const int tid = threadIdx.x;
   const int j = blockIdx.y;                       // sample (primal) or tangent index
   const int b = (MODE == MODE_PRIMAL) ? j : j / a.kps;
@@ -41,6 +43,37 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
     for (int i = tid; i < 2 * a.G; i += 256) lsum[i] = 0.f;
     __syncthreads();
   }
+  if (!STATS && a.red) {
+    // fixed-order reduction of the statistics launch's per-block partials of sample / tangent j: segment q adds blocks [q nb/4, (q+1) nb/4) in
+    // block order, then the 4 segment sums are added in order -- the same bits in every block of every run
+    const int nblk = gridDim.x, n2 = 2 * a.G;
+    const float* pj = a.part + (long)j * nblk * n2;
+    for (int t = tid; t < 4 * n2; t += 256) {
+      const int q = t / n2, i = t - q * n2;
+      const int b0 = (int)((long)nblk * q / 4), b1 = (int)((long)nblk * (q + 1) / 4);
+      double acc = 0.0;
+      for (int bb = b0; bb < b1; ++bb) acc += (double)pj[(long)bb * n2 + i];
+      lseg[q][i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+      const double acc = ((lseg[0][i] + lseg[1][i]) + lseg[2][i]) + lseg[3][i];
+      if (MODE == MODE_PRIMAL) lseg[0][i] = acc;            // raw (sum, sum of squares), finalised below
+      else lsum[i] = (float)(acc * inv_n);
+    }
+    __syncthreads();
+    if (MODE == MODE_PRIMAL) {
+      for (int g = tid; g < a.G; g += 256) {
+        const double m = lseg[0][2 * g] * inv_n;
+        double v = lseg[0][2 * g + 1] * inv_n - m * m;
+        if (v < 0) v = 0;
+        const double rs = 1.0 / sqrt(v + (double)a.eps);
+        lsum[2 * g] = (float)m; lsum[2 * g + 1] = (float)rs;
+        if (blockIdx.x == 0) { a.pstats[((long)j * a.G + g) * 2] = m; a.pstats[((long)j * a.G + g) * 2 + 1] = rs; }   // kept for the tangent / adjoint passes
+      }
+      __syncthreads();
+    }
+  }
   if (r < rpi) {
     for (int q = 0; q < ncp; ++q) {
       const int col = c0 + q * cw;
@@ -56,11 +89,15 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
         // (the per-channel form cost 48 dependent scalar loads per thread, as much as the thread's whole pixel walk)
         const int g0 = ch0 / cpg, g1 = min(g0 + 1, a.G - 1);
         float me[2] = {0.f, 0.f}, rs[2] = {0.f, 0.f}, t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
-        if (MODE != MODE_PRIMAL || !STATS) {
+        if (MODE == MODE_PRIMAL && !STATS && a.red) {
+          me[0] = lsum[2 * g0]; rs[0] = lsum[2 * g0 + 1]; me[1] = lsum[2 * g1]; rs[1] = lsum[2 * g1 + 1];
+        } else if (MODE != MODE_PRIMAL || !STATS) {
           me[0] = (float)a.pstats[((long)b * a.G + g0) * 2]; rs[0] = (float)a.pstats[((long)b * a.G + g0) * 2 + 1];
           me[1] = (float)a.pstats[((long)b * a.G + g1) * 2]; rs[1] = (float)a.pstats[((long)b * a.G + g1) * 2 + 1];
         }
-        if (MODE != MODE_PRIMAL && !STATS) {
+        if (MODE != MODE_PRIMAL && !STATS && a.red) {
+          t1[0] = lsum[2 * g0]; t2[0] = lsum[2 * g0 + 1]; t1[1] = lsum[2 * g1]; t2[1] = lsum[2 * g1 + 1];
+        } else if (MODE != MODE_PRIMAL && !STATS) {
           t1[0] = (float)(a.tstats[((long)j * a.G + g0) * 2] * inv_n); t2[0] = (float)(a.tstats[((long)j * a.G + g0) * 2 + 1] * inv_n);
           t1[1] = (float)(a.tstats[((long)j * a.G + g1) * 2] * inv_n); t2[1] = (float)(a.tstats[((long)j * a.G + g1) * 2 + 1] * inv_n);
         }
@@ -75,11 +112,15 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
         for (int e = 0; e < CH; ++e) {
           grp[e] = (ch0 + e) / cpg;
           mean[e] = rstd[e] = m1[e] = m2[e] = 0.f;
-          if (MODE != MODE_PRIMAL || !STATS) {
+          if (MODE == MODE_PRIMAL && !STATS && a.red) {
+            mean[e] = lsum[2 * grp[e]]; rstd[e] = lsum[2 * grp[e] + 1];
+          } else if (MODE != MODE_PRIMAL || !STATS) {
             mean[e] = (float)a.pstats[((long)b * a.G + grp[e]) * 2];
             rstd[e] = (float)a.pstats[((long)b * a.G + grp[e]) * 2 + 1];
           }
-          if (MODE != MODE_PRIMAL && !STATS) {
+          if (MODE != MODE_PRIMAL && !STATS && a.red) {
+            m1[e] = lsum[2 * grp[e]]; m2[e] = lsum[2 * grp[e] + 1];
+          } else if (MODE != MODE_PRIMAL && !STATS) {
             m1[e] = (float)(a.tstats[((long)j * a.G + grp[e]) * 2] * inv_n);
             m2[e] = (float)(a.tstats[((long)j * a.G + grp[e]) * 2 + 1] * inv_n);
           }
@@ -158,43 +199,15 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
   }
   if (STATS && a.det) {
     __syncthreads();
-    // ordered in-block reduction: thread i < 2G adds the rpi x cpg per-channel partials of its group, always in the same order
-    const int nblk = gridDim.x;
-    float* part = a.part + ((long)j * nblk + blockIdx.x) * 2 * a.G;
+    // ordered in-block reduction: thread i < 2G adds the rpi x cpg per-channel partials of its group, always in the same order, and stores the
+    // block's partial; the apply launch adds the blocks' partials in block order (no ticket, no fence: the kernel boundary orders them)
+    float* part = a.part + ((long)j * gridDim.x + blockIdx.x) * 2 * a.G;
     for (int i = tid; i < 2 * a.G; i += 256) {
       const int g = i >> 1, w = i & 1;
       float acc = 0.f;
       for (int rr = 0; rr < rpi; ++rr)
         for (int c = 0; c < cpg; ++c) acc += lch[((long)rr * a.C + g * cpg + c) * 2 + w];
-      __hip_atomic_store(part + i, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1) store: no L2 write-back fence needed
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this CU before the ticket is taken
-    __syncthreads();
-    if (tid == 0) {
-      const int t = atomicAdd(a.ticket + j, 1);
-      s_last = (t == nblk - 1);
-      if (s_last) a.ticket[j] = 0;           // ready for the next launch on this stream
-    }
-    __syncthreads();
-    if (s_last) {                            // the last block to arrive adds every block's partial in block order (fp64)
-      double* dst = (MODE == MODE_PRIMAL) ? a.pstats : a.tstats;
-      const float* pj = a.part + (long)j * nblk * 2 * a.G;
-      for (int i = tid; i < 2 * a.G; i += 256) {
-        double acc = 0.0;
-        for (int bb = 0; bb < nblk; ++bb) acc += (double)__hip_atomic_load(pj + (long)bb * 2 * a.G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 loads: L1 bypassed
-        dst[(long)j * a.G * 2 + i] = acc;
-      }
-      if (MODE == MODE_PRIMAL) {             // finalise (sum, sum of squares) -> (mean, rstd) in place
-        __syncthreads();
-        for (int g = tid; g < a.G; g += 256) {
-          double* st = a.pstats + ((long)j * a.G + g) * 2;
-          const double m = st[0] * inv_n;
-          double v = st[1] * inv_n - m * m;
-          if (v < 0) v = 0;
-          st[0] = m;
-          st[1] = 1.0 / sqrt(v + (double)a.eps);
-        }
-      }
+      part[i] = acc;
     }
   }
 }
@@ -375,6 +388,39 @@ static int gn_fused_groups(int C, int G, int HW, int CH, int es) {
   return 0;
 }
 
+// Large maps (more than GN_RED_MAX statistics blocks per sample: DDPM 64x64 and up, the image autoencoder): one small launch adds the per-block
+// partials in the same fixed order into the fp64 statistics (and finalises the primal ones), so the apply blocks need not each walk them.
+constexpr int GN_RED_MAX = 256;
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a, int nblk) {
+  __shared__ double lseg[4][2 * 256];
+  const int tid = threadIdx.x, j = blockIdx.x, n2 = 2 * a.G;
+  const double inv_n = 1.0 / ((double)a.HW * (a.C / a.G));
+  const float* pj = a.part + (long)j * nblk * n2;
+  for (int t = tid; t < 4 * n2; t += 256) {
+    const int q = t / n2, i = t - q * n2;
+    const int b0 = (int)((long)nblk * q / 4), b1 = (int)((long)nblk * (q + 1) / 4);
+    double acc = 0.0;
+    for (int bb = b0; bb < b1; ++bb) acc += (double)pj[(long)bb * n2 + i];
+    lseg[q][i] = acc;
+  }
+  __syncthreads();
+  double* dst = (MODE == MODE_PRIMAL) ? a.pstats : a.tstats;
+  if (MODE != MODE_PRIMAL) {
+    for (int i = tid; i < n2; i += 256) dst[(long)j * n2 + i] = ((lseg[0][i] + lseg[1][i]) + lseg[2][i]) + lseg[3][i];
+  } else {
+    for (int g = tid; g < a.G; g += 256) {
+      const double s1 = ((lseg[0][2 * g] + lseg[1][2 * g]) + lseg[2][2 * g]) + lseg[3][2 * g];
+      const double s2 = ((lseg[0][2 * g + 1] + lseg[1][2 * g + 1]) + lseg[2][2 * g + 1]) + lseg[3][2 * g + 1];
+      const double m = s1 * inv_n;
+      double v = s2 * inv_n - m * m;
+      if (v < 0) v = 0;
+      dst[((long)j * a.G + g) * 2] = m;
+      dst[((long)j * a.G + g) * 2 + 1] = 1.0 / sqrt(v + (double)a.eps);
+    }
+  }
+}
+
 __global__ void gn_finalize(double* st, int n_groups, double inv_n, double eps) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_groups) return;
@@ -406,25 +452,33 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
   if (a.det) {
     const int cols = a.C / CH, cw = cols < 256 ? cols : 256, rpi = 256 / cw;
     lds = (size_t)rpi * a.C * 2 * sizeof(float);
-    if (!a.part || !a.ticket || (size_t)grid.x * n * 2 * a.G * sizeof(float) > a.part_bytes) {
+    if (!a.part || (size_t)grid.x * n * 2 * a.G * sizeof(float) > a.part_bytes) {
       set_error("groupnorm: statistics scratch missing or too small (%u blocks x %d x %d groups)", grid.x, n, a.G);
       return -1;
     }
     if (lds > 48 * 1024) { set_error("groupnorm: C=%d needs %zu bytes of LDS for the ordered reduction", a.C, lds); return -1; }
   }           // (atomic path: the caller has zeroed pstats / tstats -- one memset per pass in the engine)
-  hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), lds, st, a, ppb);
+  GNArgs b = a;
+  b.red = a.det && (int)grid.x <= GN_RED_MAX;     // the apply blocks add the partials themselves (32 ... 256 L2-resident loads per thread quarter)
+  hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), lds, st, b, ppb);
+  if (a.det && !b.red) hipLaunchKernelGGL((gn_reduce_kernel<MODE>), dim3(n), dim3(256), 0, st, b, (int)grid.x);
   if (MODE == MODE_PRIMAL && !a.det) {
     int ng = a.Bp * a.G;
     hipLaunchKernelGGL(gn_finalize, dim3((ng + 255) / 256), dim3(256), 0, st, a.pstats, ng, 1.0 / ((double)a.HW * (a.C / a.G)), (double)a.eps);
   }
-  hipLaunchKernelGGL((gn_kernel<T, MODE, false>), grid, dim3(256), 0, st, a, ppb);
+  hipLaunchKernelGGL((gn_kernel<T, MODE, false>), grid, dim3(256), 0, st, b, ppb);
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
 int groupnorm_launches(int dtype, int mode, const GNArgs& a) {   // kernels launch_groupnorm issues (engine statistics)
   if (gn_fused_groups(a.C, a.G, a.HW, dt_chunk(dtype), dtype == DT_F32 ? 4 : 2)) return 1;
-  return (mode == MODE_PRIMAL && !a.det) ? 3 : 2;
+  if (!a.det) return mode == MODE_PRIMAL ? 3 : 2;
+  const int n = mode == MODE_PRIMAL ? a.Bp : a.NT;
+  int ppb = 64;
+  static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;
+  while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
+  return (a.HW + ppb - 1) / ppb <= GN_RED_MAX ? 2 : 3;
 }
 
 int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st) {

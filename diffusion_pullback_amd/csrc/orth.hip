@@ -4,7 +4,8 @@
 // Replaces torch.linalg.svd(v_, full_matrices=False) at reference src/utils/utils.py:799 (and :233):
 //   W = U S V^T  ->  rows of V^T (descending S) and s = sqrt(S).
 // Method: G = W W^T (k x k, fp64) -> cyclic Jacobi eigen-decomposition G = Q L Q^T on one thread
-// -> V^T = L^-1/2 Q^T W.  One streaming pass over W for G, one for V^T: HBM/L2-bound, ~2 reads + 1
+// -> V^T = L^-1/2 Q^T W.  Every reduction across blocks goes through per-block partials added in block order (no atomics: bitwise
+// reproducible).  One streaming pass over W for G, one for V^T: HBM/L2-bound, ~2 reads + 1
 // write of k*N floats.  LAPACK leaves the sign of each singular vector arbitrary; here each row is
 // signed to have non-negative overlap with the previous iterate (needs W V_prev^T, accumulated in the
 // same pass), which makes the reference's stop rule allclose(V_prev, V) well defined.
@@ -16,8 +17,9 @@ namespace dpb {
 
 constexpr int KMAX_ALL = 56;          // largest supported rank (the reference's default pca_rank is 50)
 
-// grid (nblk, k, ceil(k/16)): block (i, jt) accumulates G[i][jt*16..] and X[i][jt*16..] = W_i . Vprev_j over a slice of N
-__global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* Vp, double* G, double* X, int k, long N) {
+// grid (nblk, k, ceil(k/16)): block (b, i, jt) accumulates G[i][jt*16..] and X[i][jt*16..] = W_i . Vprev_j over its slice of N and stores them as
+// partial b: Gp[b][0 | 1][k][k] (plain stores; eig_kernel adds the partials in block order -- no atomics, bitwise reproducible)
+__global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* Vp, double* Gp, int k, long N) {
   constexpr int KMAX = 16;
   const int i = blockIdx.y, j0 = blockIdx.z * KMAX;
   double g[KMAX], x[KMAX];   // fp64 accumulation: small singular values survive the squaring in the Gram matrix
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* 
     int w = threadIdx.x / KMAX, j = threadIdx.x % KMAX;
     if (j0 + j < k) {
       double s = red[w][j][0] + red[w][j][1] + red[w][j][2] + red[w][j][3];
-      atomicAdd((w == 0 ? G : X) + i * k + j0 + j, s);
+      Gp[(((long)blockIdx.x * 2 + w) * k + i) * k + j0 + j] = s;
     }
   }
 }
@@ -56,15 +58,22 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* W, const float* 
 // one wave: parallel cyclic Jacobi eigen-solve of the symmetric k x k Gram matrix (thread r owns row/col r),
 // then the mixing matrix Cm with V_i = sum_j Cm[i][j] W_j.
 template <int KMAX>
-__global__ __launch_bounds__(64) void eig_kernel(const double* G, const double* X, double* Cm, float* s_out, int k) {
-  __shared__ double A[KMAX][KMAX + 1], Q[KMAX][KMAX + 1];
+__global__ __launch_bounds__(64) void eig_kernel(const double* Gp, int nbg, double* Cm, float* s_out, int k) {
+  __shared__ double A[KMAX][KMAX + 1], Q[KMAX][KMAX + 1], X[KMAX * KMAX];
   __shared__ int order[KMAX];
   const int r = threadIdx.x;
+  for (int e = r; e < k * k; e += 64) {          // Gram matrix and overlaps: the blocks' partials added in block order
+    double g = 0.0, x = 0.0;
+    for (int b = 0; b < nbg; ++b) { g += Gp[((long)b * 2) * k * k + e]; x += Gp[((long)b * 2 + 1) * k * k + e]; }
+    Q[e / k][e % k] = g;
+    X[e] = x;
+  }
+  __syncthreads();
   if (r < k)
-    for (int j = 0; j < k; ++j) {
-      A[r][j] = 0.5 * (G[r * k + j] + G[j * k + r]);
-      Q[r][j] = r == j ? 1.0 : 0.0;
-    }
+    for (int j = 0; j < k; ++j) A[r][j] = 0.5 * (Q[r][j] + Q[j][r]);
+  __syncthreads();
+  if (r < k)
+    for (int j = 0; j < k; ++j) Q[r][j] = r == j ? 1.0 : 0.0;
   __syncthreads();
   for (int sweep = 0; sweep < 14; ++sweep) {
     // converged when the off-diagonal mass is negligible (checked by every thread on the same data: uniform)
@@ -154,37 +163,42 @@ __global__ __launch_bounds__(256) void orth_apply_kernel(const float* W, const f
   }
   if (lane == 0) { rd[wave] = d2; rv[wave] = viol; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&acc[0], rd[0] + rd[1] + rd[2] + rd[3]);
-    float m = fmaxf(fmaxf(rv[0], rv[1]), fmaxf(rv[2], rv[3]));
-    atomicMax(reinterpret_cast<unsigned long long*>(&acc[1]), (unsigned long long)__float_as_uint(fmaxf(m, 0.f)));
+  if (threadIdx.x == 0) {                        // this block's partial (finish kernel: block order)
+    acc[2 * blockIdx.x] = ((rd[0] + rd[1]) + rd[2]) + rd[3];
+    acc[2 * blockIdx.x + 1] = (double)fmaxf(fmaxf(fmaxf(rv[0], rv[1]), fmaxf(rv[2], rv[3])), 0.f);
   }
 }
 
-__global__ void orth_finish_kernel(const double* acc, float* conv) {
-  conv[0] = (float)sqrt(acc[0]);
-  conv[1] = __uint_as_float((unsigned)(*reinterpret_cast<const unsigned long long*>(&acc[1])));
+__global__ void orth_finish_kernel(const double* acc, int nb, float* conv) {
+  double d2 = 0.0, m = 0.0;
+  for (int b = 0; b < nb; ++b) { d2 += acc[2 * b]; m = fmax(m, acc[2 * b + 1]); }
+  conv[0] = (float)sqrt(d2);
+  conv[1] = (float)m;
+}
+
+static inline unsigned orth_nb(long N) { unsigned nb = (unsigned)((N + 2047) / 2048); return nb > 512 ? 512 : (nb < 1 ? 1 : nb); }
+static inline unsigned orth_nbg(long N) { const unsigned nb = orth_nb(N); return nb > 32 ? 32 : nb; }
+size_t orth_scratch_bytes(int k, long N) {     // Cm [k][k] | Gram partials [nbg][2][k][k] | (dist^2, violation) partials [nb][2]
+  return sizeof(double) * ((size_t)k * k * (1 + 2 * orth_nbg(N)) + 2 * (size_t)orth_nb(N));
 }
 
 int launch_orth(const OrthArgs& a, hipStream_t st) {
   if (a.k < 1 || a.k > KMAX_ALL) { set_error("orth: pca_rank k=%d outside [1,%d]", a.k, KMAX_ALL); return -1; }
   const int k = a.k;
-  double* G = a.scratch;
-  double* X = G + k * k;
-  double* Cm = X + k * k;
-  double* acc = Cm + k * k;
-  DPB_CHECK(hipMemsetAsync(a.scratch, 0, sizeof(double) * (3 * k * k + 2), st));
-  unsigned nb = (unsigned)((a.N + 2047) / 2048);
-  if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(gram_kernel, dim3(nb, k, (k + 15) / 16), dim3(256), 0, st, a.W, a.Vprev, G, X, k, a.N);
+  if (a.scratch_bytes < orth_scratch_bytes(k, a.N)) { set_error("orth: scratch of %zu bytes, dpb_orth_scratch_bytes(k=%d, N=%ld) = %zu needed", a.scratch_bytes, k, a.N, orth_scratch_bytes(k, a.N)); return -1; }
+  const unsigned nb = orth_nb(a.N), nbg = orth_nbg(a.N);
+  double* Cm = a.scratch;
+  double* Gp = Cm + k * k;
+  double* acc = Gp + (size_t)2 * nbg * k * k;
+  hipLaunchKernelGGL(gram_kernel, dim3(nbg, k, (k + 15) / 16), dim3(256), 0, st, a.W, a.Vprev, Gp, k, a.N);
   if (k <= 16) {
-    hipLaunchKernelGGL((eig_kernel<16>), dim3(1), dim3(64), 0, st, G, X, Cm, a.s, k);
+    hipLaunchKernelGGL((eig_kernel<16>), dim3(1), dim3(64), 0, st, Gp, (int)nbg, Cm, a.s, k);
     hipLaunchKernelGGL((orth_apply_kernel<16>), dim3(nb), dim3(256), 0, st, a.W, a.Vprev, a.V, Cm, acc, k, a.N);
   } else {
-    hipLaunchKernelGGL((eig_kernel<KMAX_ALL>), dim3(1), dim3(64), 0, st, G, X, Cm, a.s, k);
+    hipLaunchKernelGGL((eig_kernel<KMAX_ALL>), dim3(1), dim3(64), 0, st, Gp, (int)nbg, Cm, a.s, k);
     hipLaunchKernelGGL((orth_apply_kernel<KMAX_ALL>), dim3(nb), dim3(256), 0, st, a.W, a.Vprev, a.V, Cm, acc, k, a.N);
   }
-  hipLaunchKernelGGL(orth_finish_kernel, dim3(1), dim3(1), 0, st, acc, a.conv);
+  hipLaunchKernelGGL(orth_finish_kernel, dim3(1), dim3(1), 0, st, acc, (int)nb, a.conv);
   DPB_CHECK(hipGetLastError());
   return 0;
 }

@@ -165,7 +165,7 @@ class Engine:
             V = torch.empty_like(W)
             s = torch.empty(k, dtype=torch.float32, device=self.device)
             conv = torch.empty(2, dtype=torch.float32, device=self.device)
-            scratch = torch.empty(3 * k * k + 2, dtype=torch.float64, device=self.device)
+            scratch = torch.empty(int(self.lib.dpb_orth_scratch_bytes(k, n)) // 8 + 1, dtype=torch.float64, device=self.device)
             L.check(self.lib.dpb_orth(_ptr(W), _ptr(Vprev), _ptr(V), _ptr(s), _ptr(conv), _ptr(scratch), k, n, C.c_void_p(s_)))
         return V, s, conv
 

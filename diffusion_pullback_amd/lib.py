@@ -65,6 +65,7 @@ SYMBOLS = {
     "dpb_jvp": (_I, [_P, _I, _P, _I, _P]),
     "dpb_vjp": (_I, [_P, _I, _P, _I, _P]),
     "dpb_orth": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P]),
+    "dpb_orth_scratch_bytes": (C.c_size_t, [_I, _L]),
     "dpb_pullback_iterate": (_I, [_P, _I, _P, _P, _P, _P, _I, _I]),
     "dpb_ddim_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
     "dpb_lincomb": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _P]),

@@ -118,10 +118,12 @@ int dpb_jvp(dpb_engine* e, int tap_buf, const float* V, int nt, float* U);
 int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
 
 /* Thin SVD of W [k][N] (fp32, k <= 56): V rows = right singular vectors (descending), s = sqrt(singular values),
- * conv[0] = ||V - Vprev||_2, conv[1] = max(|V - Vprev| - 1e-5|V|).  scratch: >= 8*(3*k*k+2) bytes.
+ * conv[0] = ||V - Vprev||_2, conv[1] = max(|V - Vprev| - 1e-5|V|).  scratch: device memory of >= dpb_orth_scratch_bytes(k, N) bytes (Gram
+ * matrix and distance partials per block, added in block order: the result is bitwise reproducible).
  * Replaces: torch.linalg.svd + dist/allclose inputs, utils.py:799-806.  Engine-independent. */
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
              void* hip_stream);
+size_t dpb_orth_scratch_bytes(int k, int64_t N);   /* 0 for k outside [1, 56] */
 
 /* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev, for all B samples
  * of the last dpb_primal together (independent bases, one shared weight stream; B*k <= max_tangents).
@@ -154,9 +156,10 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
 /* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
  * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands;
  * 600: halo-tile 3x3 convolution), "gemm_splitk" (n), "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block
- * order per XCD), "gn_deterministic" (0|1: GroupNorm statistics of the two-pass kernels reduced in a fixed order -> bitwise reproducible
- * runs, ~10 % slower; default 0 = atomics), "graph_iterate" (0|1: dpb_pullback_iterate replays a captured hipGraph on a non-default stream;
- * measured equal to eager launches, default 0).
+ * order per XCD), "gn_deterministic" (1, default: GroupNorm statistics of the two-pass kernels reduced in a fixed order -> bitwise
+ * reproducible runs; 0 = the round-1 atomic statistics, A/B only), "graph_iterate" (0|1: dpb_pullback_iterate replays a captured hipGraph on a non-default stream;
+ * measured equal to eager launches, default 0), "attn_shared" (bits: 1 shared-probability tangent kernel, 2 shared-probability key-major adjoint of the
+ * head-dim-40 self-attention layers; default 3, 0 = the per-tangent kernels of round 2).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
  * kernel and split count per product shape; DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
  * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L, DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN,

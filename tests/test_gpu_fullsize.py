@@ -194,10 +194,11 @@ def test_sd15_converges_under_reference_stop_rule(dtype):
 # ------------------------------------------------------------------------------------------------ BASELINE configs[3]
 def test_sd15_config3_k10_samples_advanced_together():
     """configs[3]: edit-prompt context, k = 10, several x_t samples advanced together on one GPU (one rank's share of the 64-sample
-    job): the batched run equals one-at-a-time runs, and one of the ten tangents equals the oracle JVP of that direction."""
+    job), the bench's own 12 iterations: the batched run equals one-at-a-time runs in ALL ten vectors (|cos| >= 0.99, s to 2 %), and one of
+    the ten tangents / cotangents equals the oracle JVP / VJP of that direction."""
     _threads()
     _, ctx0 = _sd15_inputs()
-    k, S, iters = 10, 4, 6
+    k, S, iters = 10, 4, 12
     g = torch.Generator().manual_seed(77)
     ctx = torch.randn(1, 77, 768, generator=g)                                   # seeded "edit prompt" embedding (not the null ctx)
     zs = torch.randn(S, 4, 64, 64, generator=g)
@@ -209,13 +210,11 @@ def test_sd15_config3_k10_samples_advanced_together():
         _, s_i, V_i, _ = net.pullback_fixed(zs[i:i + 1], T_SD, ctx, "mid", 0, k, iters, V0)
         sb, Vb = s_b[k * i:k * (i + 1)], V_b[k * i:k * (i + 1)]
         cos = abs_cos(Vb, V_i)
-        # The batched and the single launch pick different tiles / split-K factors and the two-pass GroupNorm statistics are atomic, so the
-        # two runs differ by 16-bit rounding noise; after 6 iterations that noise is still amplified in the slowest directions (sigma_10 /
-        # sigma_11 = 0.78): the leading six are held to the north-star tolerance, the full rank-10 basis as a subspace.
-        assert torch.allclose(sb[:6], s_i[:6], rtol=2e-2), (i, sb, s_i)
-        assert (cos[:6] > 0.99).all(), (i, cos)
-        assert torch.allclose(sb, s_i, rtol=1e-1), (i, sb, s_i)
-        assert torch.linalg.svdvals((Vb @ V_i.T).double().cpu()).min() > 0.97, (i, cos)
+        # the batched and the single launch pick different tiles / split-K factors (16-bit rounding differs); after the 12 iterations of the
+        # bench the slowest direction has contracted by (sigma_11 / sigma_10)^24 ~ 0.8^24 = 0.005: every vector is held to the north-star bar
+        print(i, "s batched", sb.cpu().tolist(), "single", s_i.cpu().tolist(), "|cos|", cos.tolist())
+        assert torch.allclose(sb, s_i, rtol=2e-2), (i, sb, s_i)
+        assert (cos > 0.99).all(), (i, cos)
     # distinct samples have distinct bases (the batch is not one sample repeated)
     assert abs_cos(V_b[0:1], V_b[k:k + 1]).item() < 0.99
     e = net.engine
@@ -223,6 +222,9 @@ def test_sd15_config3_k10_samples_advanced_together():
     U = e.jvp(("mid", 0), V0.to(DEV))                                             # nt = 10 tangents in one pass
     f = _oracle_f(False, ("mid", 0), ctx)
     assert rel(U[7:8], oracle_jvp(f, zs[0:1], V0[7:8])) < TOL[torch.bfloat16]
+    Uc = torch.randn(k, 81920, generator=g)
+    W = e.vjp(("mid", 0), Uc.to(DEV))                                             # nt = 10 cotangents in one pass
+    assert rel(W[3:4], oracle_vjp(f, zs[0:1], Uc[3:4])) < TOL[torch.bfloat16]
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[1]
@@ -252,3 +254,85 @@ def test_ddpm256_operator_and_oracle_fp32():
     V0 = torch.linalg.qr(torch.randn(196608, 5, generator=g))[0].T.contiguous()
     u, s, vT = net.local_encoder_pullback_xt(x, torch.tensor(t), op="mid", block_idx=0, pca_rank=5, V0=V0)
     assert net.last_iters == 12 and ((s[1:] / s[:-1]) < 0.95).all(), (net.last_iters, s)
+
+
+# ------------------------------------------------------------------------------------------------ the HEADLINE configs vs the REFERENCE's own function
+def _check_vs_reference(fix, s, vT, dtype):
+    s, vT = s.float().cpu(), vT.float().cpu()
+    cos = abs_cos(vT, fix["vT"])
+    fro = _relfro_sv(s, vT, fix["s"], fix["vT"])
+    print(dtype, "s", s.tolist(), "reference", fix["s"].tolist(), "|cos|", cos.tolist(), "relfro", fro)
+    assert ((fix["s"][1:] / fix["s"][:-1]) < 0.95).all()                       # the per-vector criterion is well conditioned
+    assert (cos > (0.9999 if dtype == torch.float32 else 0.99)).all(), cos       # north star: top-5 |cos| >= 0.99
+    assert torch.allclose(s, fix["s"], rtol=1e-3 if dtype == torch.float32 else 2e-2), (s, fix["s"])
+    assert fro < (5e-3 if dtype == torch.float32 else 5e-2), fro
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_sd15_headline_vs_reference_function_golden(dtype):
+    """BASELINE configs[2] / north star, no transitivity: the fixture holds (s, vT) RETURNED BY THE REFERENCE'S OWN
+    utils.local_encoder_pullback_zt (src/utils/utils.py:722-816) run on the CPU over the full-size SD-v1.5 net with these weights and inputs,
+    k = 5, its default stop rule capped at 12 iterations (tests/golden/make_golden_fullsize.py).  The product draws the same V0 (V0=None under
+    the recorded seed, like the reference: utils.py:750-751) and must match every one of the five vectors / values."""
+    from _util import load_golden
+    fix = load_golden("pullback_sd15_mid_k5.pt")
+    assert fix["iters"] == 12 and fix["k"] == 5
+    z, ctx = _sd15_inputs()
+    net = _sd15(dtype)
+    torch.manual_seed(fix["rng_seed"])
+    u, s, vT = net.local_encoder_pullback_zt(z, torch.tensor(T_SD), ctx, op="mid", block_idx=0, pca_rank=5, chunk_size=fix["chunk_size"],
+                                             min_iter=fix["min_iter"], max_iter=fix["max_iter"], convergence_threshold=fix["thr"])
+    assert net.last_iters == 12
+    _check_vs_reference(fix, s, vT, dtype)
+    # u = J V_prev of the last iteration (un-normalised, utils.py:810): column norms and a probe of the leading rows, sign-aligned per column
+    un = u.float().cpu().norm(dim=0)
+    assert torch.allclose(un, fix["u_norms"], rtol=1e-3 if dtype == torch.float32 else 3e-2), (un, fix["u_norms"])
+    uh, rh = u[:256].float().cpu(), fix["u_head"]
+    sign = torch.sign((uh * rh).sum(0, keepdim=True))
+    assert rel(uh * sign, rh) < (2e-3 if dtype == torch.float32 else 1e-1)
+
+
+def test_ddpm256_headline_vs_reference_function_golden():
+    """BASELINE configs[1]: (s, vT) returned by the vendored PullBackDDPM.local_encoder_pullback_xt (src/models/ddpm/diffusion.py:484-556) on the
+    full-size CelebA-HQ-256 net, k = 5, fp32, 12 iterations."""
+    from _util import load_golden
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    fix = load_golden("pullback_ddpm256_mid_k5.pt")
+    assert fix["iters"] == 12 and fix["k"] == 5
+    cfg = cf.CELEBA_HQ_256
+    params = cf.ddpm_init_params(cfg, seed=0, spectrum=cf.Spectrum())
+    net = PullbackUNet("ddpm", cfg, params, dtype=torch.float32, device=DEV, max_batch=1, max_rank=5, upto=("mid", 0), verbose=False)
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(fix["rng_seed"])
+    u, s, vT = net.local_encoder_pullback_xt(x, torch.tensor(600.0), op="mid", block_idx=0, pca_rank=5, chunk_size=fix["chunk_size"],
+                                             min_iter=fix["min_iter"], max_iter=fix["max_iter"], convergence_threshold=fix["thr"])
+    assert net.last_iters == 12
+    _check_vs_reference(fix, s, vT, torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: the criterion at down / up taps
+@pytest.mark.parametrize("tap", [("down", 1), ("up", 3)], ids=["down1", "up3"])
+def test_sd15_config4_top5_fp16_vs_fp32_at_down_and_up_taps(tap):
+    """configs[4] (down / up sweep, fp16): the mid-block shaping is not in the prefix of a down tap, so Spectrum.for_tap also shapes the last
+    self-attention INSIDE the tap's prefix; the top-5 criterion (|cos| >= 0.99 per vector, fp16 vs fp32, 12 iterations, identical seeded
+    inputs) is then well conditioned at the tap (asserted) and asserted."""
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    z, ctx = _sd15_inputs()
+    k = 5
+    sp = cf.Spectrum.for_tap(*tap)
+    params = cf.sd_init_params(cf.SD15, seed=0, only_prefix=ENC if tap[0] == "down" else None, spectrum=sp)
+    V0 = torch.linalg.qr(torch.randn(16384, k, generator=torch.Generator().manual_seed(0)))[0].T.contiguous()
+    out = {}
+    for dtype in (torch.float32, torch.float16):
+        net = PullbackUNet("sd", cf.SD15, params, dtype=dtype, device=DEV, max_batch=1, max_rank=k, upto=tap, verbose=False)
+        _, s, v, _ = net.pullback_fixed(z, T_SD, ctx, tap[0], tap[1], k, 12, V0)
+        out[dtype] = (s.clone().cpu(), v.clone().cpu())
+        del net
+        torch.cuda.empty_cache()
+    (s32, v32), (s16, v16) = out[torch.float32], out[torch.float16]
+    cos = abs_cos(v16, v32)
+    print(tap, "sigma fp32", s32.tolist(), "fp16", s16.tolist(), "|cos|", cos.tolist())
+    assert ((s32[1:] / s32[:-1]) < 0.95).all(), f"spectrum not separated at {tap}: {s32.tolist()}"
+    assert (cos > 0.99).all(), cos
+    assert torch.allclose(s16, s32, rtol=1e-2), (s16, s32)
+    assert _relfro_sv(s16, v16, s32, v32) < 5e-2

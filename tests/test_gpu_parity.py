@@ -123,7 +123,7 @@ def test_orth_matches_svd():
         _, s_ref, V_ref = torch.linalg.svd(W.double(), full_matrices=False)
         Wd, Vpd = W.cuda(), Vp.cuda()
         V = torch.empty_like(Wd); s = torch.empty(k, device="cuda"); conv = torch.empty(2, device="cuda")
-        scratch = torch.empty(3 * k * k + 2, dtype=torch.float64, device="cuda")
+        scratch = torch.empty(int(lib.dpb_orth_scratch_bytes(k, n)) // 8 + 1, dtype=torch.float64, device="cuda")
         L.check(lib.dpb_orth(Wd.data_ptr(), Vpd.data_ptr(), V.data_ptr(), s.data_ptr(), conv.data_ptr(), scratch.data_ptr(), k, n,
                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()

@@ -61,13 +61,8 @@ def test_sd15_vae_full_size_roundtrip_shapes():
     from diffusion_pullback_amd import configs as cf
     p, net = _mk(cf.SD15_VAE, torch.bfloat16, seed=2)
     z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(2))
-    from diffusion_pullback_amd import lib as L
-    L.check(L.load().dpb_debug_set(b"gn_deterministic", 1))      # ordered GroupNorm statistics: bitwise repeatable runs
-    try:
-        a = net.decode(z)
-        b = net.decode(z)
-    finally:
-        L.check(L.load().dpb_debug_set(b"gn_deterministic", 0))
+    a = net.decode(z)                                             # fixed-order GroupNorm statistics (default): bitwise repeatable runs,
+    b = net.decode(z)                                             # here through the large-map path (gn_reduce_kernel: 4096 statistics blocks)
     assert a.shape == (1, 3, 512, 512) and torch.isfinite(a).all()
     assert torch.equal(a, b)
     m = net.encode_moments(a.clamp(-1, 1))
