@@ -63,7 +63,11 @@ def parse():
     ap.add_argument("--no-unet-forward", action="store_true", help="skip the DDIM-loop leg (full SD-1.5 U-Net forwards at B = 1 / 2 / 5)")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the BASELINE configs[3] leg (64 samples, k = 10, edit ctx, sharded over the ranks)")
     ap.add_argument("--strong-samples", type=int, default=64)
-    return ap.parse_args()
+    ap.add_argument("--profile-run", action="store_true", help="for rocprofv3 runs: headline region only, once (no repeats, no extra legs, no CPU baseline)")
+    a = ap.parse_args()
+    if a.profile_run:
+        a.repeats, a.no_cpu_baseline, a.no_roofline, a.no_unet_forward, a.no_strong_leg = 1, True, True, True, True
+    return a
 
 
 def make_workload(name, dtype, device, k, spg, tap=("mid", 0), ctx_kind="null", shaped=True):
@@ -494,6 +498,42 @@ def main():
             res["unet_forward"] = unet_forward_leg(a, dev, dtype, dname, t, ctx, not a.no_cpu_baseline and world == 1)
         except Exception as ex:
             res["unet_forward"] = {"error": repr(ex)[:300]}
+
+    if rank == 0 and not a.no_roofline and not strong and S == 1 and a.workload == "sd15":
+        # ---- two independent samples in flight on two HIP streams (two engines over the SAME weights, own workspaces): what a per-sample job
+        # scheduler -- the reference launches one process per sample -- gets from one GPU when the one-sample pass leaves it latency-bound.
+        # Reported next to `value` (one sample at a time, one stream), never instead of it.
+        try:
+            from diffusion_pullback_amd.engine import Engine
+            cfgm = net.config
+            eB = Engine(eng.tape, cfgm.block_out_channels[0], True, False, cfgm.in_channels, 1, k)
+            sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            xa = torch.randn(2, *shape, generator=torch.Generator().manual_seed(91)).to(dev)
+            c1 = ctx.to(dev)
+            torch.cuda.synchronize(dev)
+
+            def pair(n_it):
+                Vs = []
+                for e_, st_, j in ((eng, sA, 0), (eB, sB, 1)):
+                    with torch.cuda.stream(st_):
+                        e_.primal(xa[j:j + 1], t, c1, tap)
+                        Vs.append(V0.to(dev).clone())
+                for _ in range(n_it):
+                    for e_, st_, j in ((eng, sA, 0), (eB, sB, 1)):
+                        with torch.cuda.stream(st_):
+                            e_.iterate(tap, Vs[j], 1)
+                return Vs
+            pair(2)
+            torch.cuda.synchronize(dev); t2 = time.perf_counter()
+            for _ in range(3):
+                Vs = pair(ITERS_PER_SAMPLE)
+            torch.cuda.synchronize(dev)
+            res["two_stream_throughput"] = {"value": 3 * 2 * ITERS_PER_SAMPLE / (time.perf_counter() - t2), "unit": "iters/s", "streams": 2,
+                                            "finite": bool(torch.isfinite(Vs[0]).all() and torch.isfinite(Vs[1]).all()),
+                                            "note": "3 x (primal + 12 iterations) of 2 independent samples, one per HIP stream, launches interleaved per iteration; not the headline value"}
+            del eB
+        except Exception as ex:
+            res["two_stream_throughput"] = {"error": repr(ex)[:200]}
 
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         # ---- CPU baseline: the oracle (same jacfwd / functional.jacobian / svd calls as the reference), fp32, same

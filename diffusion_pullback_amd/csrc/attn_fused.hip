@@ -23,6 +23,7 @@
 
 namespace dpb {
 
+#define DPB_ATT_PAD 8     // row padding (bf16 elements) of the LDS [row][d] tiles (16 / 24 measured in round 3: 9.02 / 9.28 vs 8.99 ms per iteration)
 
 constexpr int att_waves(int d) { return d > 80 ? 4 : 8; }   // waves per block: 8 x 32 = 256 outer rows share every streamed tile
                                                             // (head dim 160: 4 waves, the fragments need the 512-register budget)
@@ -35,7 +36,7 @@ template <int D, int W = att_waves(D)> struct FA {
   static constexpr int DO = ND * 32;
   static constexpr int BI = D <= 80 ? 128 : 64;  // inner rows per LDS stage: at 128 the one-stage-ahead register prefetch has
                                                 // twice the MFMA time to land (key-major adjoint -8 %); head dim 160 would exceed the LDS
-  static constexpr int LDR = (DP > DO ? DP : DO) + 8;   // LDS stride of [row][d] tiles (bf16 elements): 36 / 52 / 84 dwords = 4 x odd, so
+  static constexpr int LDR = (DP > DO ? DP : DO) + DPB_ATT_PAD;   // LDS stride of [row][d] tiles (bf16 elements): 36 / 52 / 84 dwords = 4 x odd, so
                                                 // ds_read_b128 fragment reads are conflict-free; >= DO columns so that the transpose
                                                 // reads of lds_tr_frag stay inside the row (columns DP.. are never consumed)
   static constexpr int LDT = BI + 4;            // LDS stride of [d][row] tiles: 68 elements = 34 dwords = 2*odd, so the 32 rows of a
@@ -381,190 +382,6 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
           w[i] = H16<FL>::pack2(v0, v1);
         }
         *reinterpret_cast<uint2*>(dOp + col) = make_uint2(w[0], w[1]);
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ tangent, probabilities shared by the tangents of a sample
-// The probabilities P depend on the primal sample only, yet every (tangent, head) block of attn_jvp_kernel recomputes S = Q K^T and its exp()
-// (VALU-bound at d = 40: 650 VALU vs 544 MFMA cycles per wave and 32 keys).  Here one block owns 64 queries of one (sample, head) and ALL TJ
-// tangents of the sample: 2 PRODUCER waves (one per 32-query group) compute P tile by tile -- K fragments straight from global / L2 in MFMA
-// operand layout, one stage ahead -- and publish it as packed 16-bit B fragments in LDS; 2 x TJ CONSUMER waves (query group g, tangent t) read
-// it back (same lane <-> query layout, 2 ds_read_b128), form X = P o dS with their own dS = scale (dQ_t K^T + Q dK_t^T) and accumulate
-// dO_t = X V + P dV_t.  Per 32 keys and tangent: 14 MFMAs + ~290 VALU cycles instead of 17 + 650, 16 exp per 5 tangents instead of 80; 12 waves
-// per CU (3 per SIMD) interleave each other's MFMA and VALU phases, and the 64 x 64-level grid at k = 5 is 512 blocks = exactly two rounds of the
-// 256 CUs (attn_jvp_kernel: 2.5).  Streams 2 + 2 TJ row tiles of 64 keys per stage (K, V, dK_t, dV_t), register-staged like the kernels above.
-template <int D, int TJ> struct SH {
-  static constexpr int QG = 2, NP = QG, NW = NP + QG * TJ, NT = NW * 64;
-  static constexpr int BI = 64;                                     // keys per LDS stage (two 32-key blocks)
-  static constexpr int NS = (D + 15) / 16, DP = NS * 16, ND = (D + 31) / 32, DO = ND * 32;
-  static constexpr int LDR = (DP > DO ? DP : DO) + 8, ROW_ELEMS = BI * LDR;
-  static constexpr int NTILE = 2 + 2 * TJ, CPR = DP / 8;            // tile 0 K, 1 V, 2 + 2t dK_t, 3 + 2t dV_t; 16-byte chunks per tile row
-  static constexpr int NLD = NTILE / 2;                             // loads per thread and stage: load i covers the tile pair (2i, 2i + 1)
-  static_assert(2 * BI * CPR == NT, "one load per thread covers exactly one pair of tiles");
-};
-
-template <int D, int TJ, int FL>
-__global__ __launch_bounds__((SH<D, TJ>::NT)) void attn_jvp_shared_kernel(FusedArgs a) {
-  using S = SH<D, TJ>;
-  __shared__ __attribute__((aligned(16))) bf16 sm[S::NTILE * S::ROW_ELEMS];
-  __shared__ __attribute__((aligned(16))) uint4 sP[2][2][S::QG][2][64];          // [stage parity][32-key block][query group][fragment][lane]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int ngrp = (a.kps + TJ - 1) / TJ;
-  const int grp = blockIdx.y % ngrp, bh = blockIdx.y / ngrp, b = bh / a.H, h = bh % a.H;
-  const int j0 = b * a.kps + grp * TJ, nj = min(TJ, a.kps - grp * TJ);
-  const long LC = (long)a.L * a.C, LCo = (long)a.L * a.Co;
-  const bf16* Kp = a.K + b * LC + h * D;
-  // ---- tile loader: thread -> (tile parity, row, chunk) fixed; load i moves tiles (2i, 2i + 1)
-  const int lt = tid >= S::BI * S::CPR ? 1 : 0;
-  const int lrow = (tid % (S::BI * S::CPR)) / S::CPR, lcc = (tid % S::CPR) * 8;
-  const bf16* lsrc[S::NLD];
-#pragma unroll
-  for (int i = 0; i < S::NLD; ++i) {
-    const bf16* base = nullptr;
-    if (i == 0) base = (lt ? a.V : a.K) + b * LC;
-    else if (i - 1 < nj) base = (lt ? a.dV : a.dK) + (long)(j0 + i - 1) * LC;
-    lsrc[i] = (base && lcc < D) ? base + h * D + (long)lrow * a.C + lcc : nullptr;
-  }
-  uint4 rg[S::NLD];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < S::NLD; ++i) rg[i] = lsrc[i] ? *reinterpret_cast<const uint4*>(lsrc[i] + (long)k0 * a.C) : make_uint4(0, 0, 0, 0);
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < S::NLD; ++i) *reinterpret_cast<uint4*>(sm + (2 * i + lt) * S::ROW_ELEMS + lrow * S::LDR + lcc) = rg[i];
-  };
-  // ---- roles.  Each role runs its OWN copy of the stage loop (same barrier sequence), so that the producers' look-ahead registers and the
-  // consumers' accumulators never live in the same allocation
-  const bool producer = wave < S::NP;
-  const int g = producer ? wave : (wave - S::NP) % S::QG;                         // 32-query group
-  const int t = producer ? 0 : (wave - S::NP) / S::QG;                            // tangent slot of a consumer wave
-  const int q = blockIdx.x * (S::QG * 32) + g * 32 + l31;
-  const float c2 = a.scale * 1.44269504088896f;
-  const int nst = a.L / S::BI;
-  bf16x8 qf[S::NS];
-  load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
-  fetch(0);
-  if (producer) {
-    const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
-    const float m2 = st[0] * 1.44269504088896f, il = st[1];
-    bf16x8 kfn[2][S::NS];                                                          // K fragments of the stage computed next
-    auto load_k = [&](int k0) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int st_ = 0; st_ < S::NS; ++st_) {
-          const int col = st_ * 16 + lhi * 8;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (col < D) v = *reinterpret_cast<const uint4*>(Kp + (long)(k0 + kb * 32 + l31) * a.C + col);
-          kfn[kb][st_] = *reinterpret_cast<bf16x8*>(&v);
-        }
-    };
-    auto produce = [&](int par) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 sc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-#pragma unroll
-        for (int st_ = 0; st_ < S::NS; ++st_) sc = MFMA(kfn[kb][st_], qf[st_], sc);
-        float p[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c2 * sc[r] - m2) * il;
-        bf16x8 pb[2];
-        pack_b<FL>(p, pb);
-        sP[par][kb][g][0][lane] = *reinterpret_cast<uint4*>(&pb[0]);
-        sP[par][kb][g][1][lane] = *reinterpret_cast<uint4*>(&pb[1]);
-      }
-    };
-    load_k(0);
-    produce(0);
-    if (nst > 1) load_k(S::BI);
-    for (int s = 0; s < nst; ++s) {
-      __syncthreads();                                // stage s-1 consumed (tiles and sP[(s-1)&1]); sP[s&1] published
-      commit();
-      __syncthreads();
-      if (s + 1 < nst) {
-        fetch((s + 1) * S::BI);                       // next stage's tiles in flight under this stage's arithmetic
-        produce((s + 1) & 1);
-        if (s + 2 < nst) load_k((s + 2) * S::BI);
-      }
-    }
-    return;
-  }
-  bf16x8 dqf[S::NS];
-#pragma unroll
-  for (int st_ = 0; st_ < S::NS; ++st_) dqf[st_] = bf16x8{};
-  if (t < nj) load_outer_frags<D>(a.dQ + (long)(j0 + t) * LC + (long)q * a.C + h * D, dqf, lhi);
-  f32x16 acc[S::ND];
-#pragma unroll
-  for (int d = 0; d < S::ND; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-  float delta = 0.f;
-  const bf16* sK = sm;
-  const bf16* sV = sm + S::ROW_ELEMS;
-  const bf16* sdK = sm + (2 + 2 * t) * S::ROW_ELEMS;
-  const bf16* sdV = sm + (3 + 2 * t) * S::ROW_ELEMS;
-  for (int s = 0; s < nst; ++s) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (s + 1 < nst) fetch((s + 1) * S::BI);
-    if (t < nj) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 ds;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = 0.f;
-#pragma unroll
-        for (int st_ = 0; st_ < S::NS; ++st_) {
-          const bf16x8 kf = lds_a_frag(sK, kb * 32 + l31, S::LDR, st_ * 16 + lhi * 8);
-          const bf16x8 dkf = lds_a_frag(sdK, kb * 32 + l31, S::LDR, st_ * 16 + lhi * 8);
-          ds = MFMA(kf, dqf[st_], ds);
-          ds = MFMA(dkf, qf[st_], ds);
-        }
-        uint4 pw[2] = {sP[s & 1][kb][g][0][lane], sP[s & 1][kb][g][1][lane]};
-        const unsigned w[8] = {pw[0].x, pw[0].y, pw[0].z, pw[0].w, pw[1].x, pw[1].y, pw[1].z, pw[1].w};
-        float x[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          x[2 * i] = H16<FL>::lo(w[i]) * (a.scale * ds[2 * i]);
-          x[2 * i + 1] = H16<FL>::hi(w[i]) * (a.scale * ds[2 * i + 1]);
-          delta += x[2 * i] + x[2 * i + 1];
-        }
-        bf16x8 xb[2];
-        pack_b<FL>(x, xb);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int d = 0; d < S::ND; ++d) {
-            acc[d] = MFMA(lds_tr_frag(sV, S::LDR, kb * 32 + ks * 16, d * 32, lane), xb[ks], acc[d]);
-            acc[d] = MFMA(lds_tr_frag(sdV, S::LDR, kb * 32 + ks * 16, d * 32, lane), *reinterpret_cast<bf16x8*>(&pw[ks]), acc[d]);
-          }
-      }
-    }
-  }
-  if (t >= nj) return;
-  delta += __shfl_xor(delta, 32, 64);
-  const bf16* Op = a.O + b * LCo + (long)q * a.Co + h * D;
-  bf16* dOp = a.dO + (long)(j0 + t) * LCo + (long)q * a.Co + h * D;
-#pragma unroll
-  for (int d = 0; d < S::ND; ++d)
-#pragma unroll
-    for (int gg = 0; gg < 4; ++gg) {
-      const int col = d * 32 + 8 * gg + 4 * lhi;
-      if (col < D) {
-        uint2 ov = *reinterpret_cast<const uint2*>(Op + col);
-        unsigned ow[2] = {ov.x, ov.y};
-        unsigned wo[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const float o0 = H16<FL>::lo(ow[i]), o1 = H16<FL>::hi(ow[i]);
-          wo[i] = H16<FL>::pack2(acc[d][gg * 4 + 2 * i] - delta * o0, acc[d][gg * 4 + 2 * i + 1] - delta * o1);
-        }
-        *reinterpret_cast<uint2*>(dOp + col) = make_uint2(wo[0], wo[1]);
       }
     }
 }
@@ -927,16 +744,24 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(FusedArgs a, int nt) {
 }
 
 // ------------------------------------------------------------------------------------------------ adjoint, key-major, probabilities shared by the cotangents of a sample
-// Same construction as attn_jvp_shared_kernel for (gK, gV): one block owns 64 KEYS of one (sample, head) and all TJ cotangents.  Producer waves
-// (one per 32-key group, K fragments in registers) compute P^T tile by tile from Q fragments and the row statistics read straight from global / L2,
-// one stage ahead; consumer waves (key group g, cotangent t: V fragments in registers) read it back, form gS_t = P o (gO_t V^T - D_t) and accumulate
-// gV_t += P^T gO_t, gK_t += scale gS_t^T Q.  Per 32 queries and cotangent: 11 MFMAs + ~230 VALU cycles instead of 14 + 640.  Streams 1 + TJ row
-// tiles of 64 queries per stage (Q, gO_t) and the TJ x 64 row dots D_t = gO_t . O.
+// The probabilities P depend on the primal sample only, yet every (cotangent, head) block of attn_adj_kv_kernel recomputes S = Q K^T and its exp().
+// Here one block owns 64 KEYS of one (sample, head) and ALL TJ cotangents of the sample: 2 PRODUCER waves (one per 32-key group, K fragments in
+// registers) compute P^T tile by tile -- Q fragments and the row statistics read straight from global / L2 in MFMA operand layout, one stage ahead --
+// and publish it as packed 16-bit B fragments in LDS; 2 x TJ CONSUMER waves (key group g, cotangent t: V fragments in registers) read it back (same
+// lane <-> key layout, 2 ds_read_b128), form gS_t = P o (gO_t V^T - D_t) and accumulate gV_t += P^T gO_t, gK_t += scale gS_t^T Q.  Per 32 queries
+// and cotangent: 11 MFMAs + ~230 VALU cycles instead of 14 + 640; the 64 x 64-level grid at k = 5 is 512 blocks = exactly two rounds of the 256 CUs.
+// Streams 1 + TJ row tiles of 64 queries per stage (Q, gO_t) through a double-buffered LDS ring (the LDS writes of stage s+1 run under the arithmetic
+// of stage s; one barrier per stage) and the TJ x 64 row dots D_t = gO_t . O (attn_rowdot_kernel).  Measured 421 -> 326 us per launch (k = 5).
+// Each role runs its OWN copy of the stage loop (same barrier sequence): the producers' look-ahead registers and the consumers' accumulators never
+// share an allocation (one loop for both: 303 spilled VGPRs).
+// (The same construction for the TANGENT kernel -- 2 + 2 TJ tiles per stage: K, V, dK_t, dV_t -- was built and measured in round 3: 420 us single-
+// buffered, 435 us double-buffered against 398 us for attn_jvp_kernel; its per-tangent dK_t / dV_t fragment reads keep the LDS pipe as busy as
+// before while 12-wave barriers add waits (SQ_WAIT_ANY 13 % -> 44 %).  Removed; LDS row paddings of 16 / 24 elements instead of 8: no gain either.)
 template <int D, int TJ> struct SHK {
   static constexpr int QG = 2, NP = QG, NW = NP + QG * TJ, NT = NW * 64;
-  static constexpr int BI = 64;
+  static constexpr int BI = 64;                                     // queries per LDS stage (two 32-query blocks); the stage ring is double-buffered
   static constexpr int NS = (D + 15) / 16, DP = NS * 16, ND = (D + 31) / 32, DO = ND * 32;
-  static constexpr int LDR = (DP > DO ? DP : DO) + 8, ROW_ELEMS = BI * LDR;
+  static constexpr int LDR = (DP > DO ? DP : DO) + DPB_ATT_PAD, ROW_ELEMS = BI * LDR;
   static constexpr int NTILE = 1 + TJ, CPR = DP / 8;                // tile 0 Q, 1 + t gO_t
   static constexpr int NLD = NTILE / 2;
   static_assert(NTILE % 2 == 0 && 2 * BI * CPR == NT, "one load per thread covers exactly one pair of tiles");
@@ -945,9 +770,9 @@ template <int D, int TJ> struct SHK {
 template <int D, int TJ, int FL>
 __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(FusedArgs a) {
   using S = SHK<D, TJ>;
-  __shared__ __attribute__((aligned(16))) bf16 sm[S::NTILE * S::ROW_ELEMS];
-  __shared__ __attribute__((aligned(16))) uint4 sP[2][2][S::QG][2][64];          // [stage parity][32-query block][key group][fragment][lane]
-  __shared__ float sD[TJ][S::BI];                                                  // D_t of the stage's queries
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * S::NTILE * S::ROW_ELEMS];    // [stage parity][tile][query][d]
+  __shared__ __attribute__((aligned(16))) uint4 sP[2][2][S::QG][2][64];            // [stage parity][32-query block][key group][fragment][lane]
+  __shared__ float sD[2][TJ][S::BI];                                                // [stage parity] D_t of the stage's queries
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int ngrp = (a.kps + TJ - 1) / TJ;
   const int grp = blockIdx.y % ngrp, bh = blockIdx.y / ngrp, b = bh / a.H, h = bh % a.H;
@@ -971,18 +796,19 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
   }
   uint4 rg[S::NLD];
   float dreg = 0.f;
-  const int dt_ = tid / S::BI, dq_ = tid % S::BI;                                 // row-dot duty: thread < TJ * BI computes D_{dt_}(q0 + dq_)
+  const int dt_ = tid / S::BI, dq_ = tid % S::BI;                                 // row-dot duty: thread < TJ * BI forwards D_{dt_}(q0 + dq_)
   auto fetch = [&](int q0) {
 #pragma unroll
     for (int i = 0; i < S::NLD; ++i) rg[i] = lsrc[i] ? *reinterpret_cast<const uint4*>(lsrc[i] + (long)q0 * lstr[i]) : make_uint4(0, 0, 0, 0);
-    if (dt_ < nj) dreg = a.Drow[((long)(j0 + dt_) * a.H + h) * a.L + q0 + dq_];   // D_t = gO_t . O per query (attn_rowdot_kernel), consumed at the next commit
+    if (dt_ < nj) dreg = a.Drow[((long)(j0 + dt_) * a.H + h) * a.L + q0 + dq_];   // D_t = gO_t . O per query (attn_rowdot_kernel)
   };
-  auto commit = [&]() {
+  auto commit = [&](int par) {
 #pragma unroll
-    for (int i = 0; i < S::NLD; ++i) *reinterpret_cast<uint4*>(sm + (2 * i + lt) * S::ROW_ELEMS + lrow * S::LDR + lcc) = rg[i];
-    if (dt_ < TJ) sD[dt_][dq_] = dreg;
+    for (int i = 0; i < S::NLD; ++i)
+      *reinterpret_cast<uint4*>(sm + (par * S::NTILE + 2 * i + lt) * S::ROW_ELEMS + lrow * S::LDR + lcc) = rg[i];
+    if (dt_ < TJ) sD[par][dt_][dq_] = dreg;
   };
-  // ---- roles (each with its own copy of the stage loop, same barrier sequence: see attn_jvp_shared_kernel)
+  // ---- roles (own copy of the stage loop each, same barrier sequence)
   const bool producer = wave < S::NP;
   const int g = producer ? wave : (wave - S::NP) % S::QG;                         // 32-key group
   const int t = producer ? 0 : (wave - S::NP) / S::QG;                            // cotangent slot of a consumer wave
@@ -992,6 +818,8 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
   bf16x8 of[S::NS];                                                                // producer: K fragments; consumer: V fragments (outer rows = keys)
   load_outer_frags<D>((producer ? a.K : a.V) + b * LC + (long)key * a.C + h * D, of, lhi);
   fetch(0);
+  commit(0);
+  if (nst > 1) fetch(S::BI);
   if (producer) {
     bf16x8 qfn[2][S::NS];                                                          // Q fragments (A operand) of the stage computed next
     float4 stn[2][8];                                                              // ... and its row statistics: (m, 1/l) of 16 queries per 32-query block
@@ -1039,15 +867,15 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
     load_q(0);
     produce(0);
     if (nst > 1) load_q(S::BI);
+    __syncthreads();
     for (int s = 0; s < nst; ++s) {
-      __syncthreads();
-      commit();
-      __syncthreads();
       if (s + 1 < nst) {
-        fetch((s + 1) * S::BI);
+        commit((s + 1) & 1);
+        if (s + 2 < nst) fetch((s + 2) * S::BI);
         produce((s + 1) & 1);
         if (s + 2 < nst) load_q((s + 2) * S::BI);
       }
+      __syncthreads();
     }
     return;
   }
@@ -1056,14 +884,15 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
   for (int d = 0; d < S::ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
-  const bf16* sQ = sm;
-  const bf16* sgO = sm + (1 + t) * S::ROW_ELEMS;
+  __syncthreads();
   for (int s = 0; s < nst; ++s) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (s + 1 < nst) fetch((s + 1) * S::BI);
+    if (s + 1 < nst) {
+      commit((s + 1) & 1);
+      if (s + 2 < nst) fetch((s + 2) * S::BI);
+    }
     if (t < nj) {
+      const bf16* sQ = sm + (s & 1) * S::NTILE * S::ROW_ELEMS;
+      const bf16* sgO = sQ + (1 + t) * S::ROW_ELEMS;
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         f32x16 gp;
@@ -1078,8 +907,8 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
         for (int i = 0; i < 8; ++i) {
           const int r0 = 2 * i, r1 = 2 * i + 1;
           const int q0i = qb * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi;
-          gs[r0] = H16<FL>::lo(w[i]) * (gp[r0] - sD[t][q0i]);
-          gs[r1] = H16<FL>::hi(w[i]) * (gp[r1] - sD[t][q0i + 1]);
+          gs[r0] = H16<FL>::lo(w[i]) * (gp[r0] - sD[s & 1][t][q0i]);
+          gs[r1] = H16<FL>::hi(w[i]) * (gp[r1] - sD[s & 1][t][q0i + 1]);
         }
         bf16x8 gsb[2];
         pack_b<FL>(gs, gsb);
@@ -1092,6 +921,7 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
           }
       }
     }
+    __syncthreads();
   }
   if (t >= nj) return;
   bf16* gKp = a.gK + (long)(j0 + t) * LC + (long)key * a.C + h * D;
@@ -1325,8 +1155,8 @@ int launch_row_stats(int fl, const void* S, float* stats, long nrows, int Lk, in
   return 0;
 }
 
-// shared-P kernels of the d = 40 layers: bit 0 tangent, bit 1 key-major adjoint (A/B switch: DPB_ATTN_SHARED, dpb_debug_set("attn_shared"))
-static int g_attn_shared = getenv("DPB_ATTN_SHARED") ? atoi(getenv("DPB_ATTN_SHARED")) : 3;
+// shared-P key-major adjoint of the d = 40 layers: bit 1 (A/B switch: DPB_ATTN_SHARED, dpb_debug_set("attn_shared"); bit 0 was the tangent variant)
+static int g_attn_shared = getenv("DPB_ATTN_SHARED") ? atoi(getenv("DPB_ATTN_SHARED")) : 2;
 void attn_debug_shared(int bits) { g_attn_shared = bits; }
 
 static int attn_xcd_on() { static int on = getenv("DPB_ATTN_XCD") ? atoi(getenv("DPB_ATTN_XCD")) : 0; return on; }
@@ -1366,16 +1196,6 @@ static int att_block_waves(int d, int L, int pairs) {
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
   if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
-  const int shared = g_attn_shared;
-  if (f.d == 40 && (shared & 1) && f.L % 64 == 0 && f.kps >= 4 && nt % f.kps == 0) {   // (kps < 4: too many idle tangent slots in a group of 5)
-    constexpr int TJ = 5;
-    const int ngrp = (f.kps + TJ - 1) / TJ;
-    const dim3 gs(f.L / 64, (nt / f.kps) * f.H * ngrp);
-    if (f.fl) hipLaunchKernelGGL((attn_jvp_shared_kernel<40, TJ, 1>), gs, dim3(SH<40, TJ>::NT), 0, st, a);
-    else hipLaunchKernelGGL((attn_jvp_shared_kernel<40, TJ, 0>), gs, dim3(SH<40, TJ>::NT), 0, st, a);
-    DPB_CHECK(hipGetLastError());
-    return 0;
-  }
   if (att_block_waves(f.d, f.L, nt * f.H) == 4 && f.d == 40) {
     dim3 g4(f.L / 128, nt * f.H);
     if (f.fl) hipLaunchKernelGGL((attn_jvp_kernel<40, 1, 4>), g4, dim3(256), 0, st, a);

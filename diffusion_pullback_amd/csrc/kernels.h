@@ -118,7 +118,7 @@ struct FusedAttnArgs {
   float scale = 1.f;
 };
 int fused_attention_supported(int dtype, int d, int L, int kv_const);
-void attn_debug_shared(int bits);   // bit 0: shared-P tangent kernel, bit 1: shared-P key-major adjoint (d = 40 layers); default 3
+void attn_debug_shared(int bits);   // bit 1: shared-P key-major adjoint of the d = 40 layers (default 2; 0 = per-cotangent kernel)
 // constant-K/V (cross) attention tangent / adjoint in one launch (attn_fused.hip): Y = c_out [P o (c_in X A^T - delta)] B
 struct CrossAttnArgs {
   const void *Q = nullptr, *K = nullptr, *V = nullptr;   // primal q [B][L][C]; k, v [B][Lk][Ck] (column windows allowed)

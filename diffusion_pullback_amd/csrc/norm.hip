@@ -52,7 +52,13 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
       const int q = t / n2, i = t - q * n2;
       const int b0 = (int)((long)nblk * q / 4), b1 = (int)((long)nblk * (q + 1) / 4);
       double acc = 0.0;
-      for (int bb = b0; bb < b1; ++bb) acc += (double)pj[(long)bb * n2 + i];
+      for (int bb = b0; bb < b1; bb += 32) {            // 32 independent L2-resident loads in flight, then added in block order
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = bb + u < b1 ? pj[(long)(bb + u) * n2 + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += (double)v[u];
+      }
       lseg[q][i] = acc;
     }
     __syncthreads();
@@ -168,7 +174,16 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
           Vec<T>::store(yp, o);
         }
       }
-      if (STATS && a.det) {
+      if (STATS && a.det && cpg >= CH) {
+        // a 16-byte chunk spans at most two groups: two (sum, sum) pairs per thread, [row][chunk column][slot] in LDS
+        float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (grp[e] == grp[0]) { p0 += s1[e]; p1 += s2[e]; } else { q0 += s1[e]; q1 += s2[e]; }
+        }
+        float4* lp = reinterpret_cast<float4*>(lch);
+        lp[(long)r * cols + col] = make_float4(p0, p1, q0, q1);
+      } else if (STATS && a.det) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
           lch[((long)r * a.C + ch0 + e) * 2] = s1[e];
@@ -205,8 +220,16 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
     for (int i = tid; i < 2 * a.G; i += 256) {
       const int g = i >> 1, w = i & 1;
       float acc = 0.f;
-      for (int rr = 0; rr < rpi; ++rr)
-        for (int c = 0; c < cpg; ++c) acc += lch[((long)rr * a.C + g * cpg + c) * 2 + w];
+      if (cpg >= CH) {                                  // chunk columns touching group g, rows in order; slot 0 = the chunk's first group
+        const int c_lo = g * cpg / CH, c_hi = (g * cpg + cpg - 1) / CH;
+        for (int c = c_lo; c <= c_hi; ++c) {
+          const int slot = (c * CH / cpg == g) ? 0 : 2;
+          for (int rr = 0; rr < rpi; ++rr) acc += lch[((long)rr * cols + c) * 4 + slot + w];
+        }
+      } else {
+        for (int rr = 0; rr < rpi; ++rr)
+          for (int c = 0; c < cpg; ++c) acc += lch[((long)rr * a.C + g * cpg + c) * 2 + w];
+      }
       part[i] = acc;
     }
   }

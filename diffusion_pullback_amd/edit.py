@@ -28,6 +28,7 @@ from typing import Optional
 
 import torch
 
+from . import timing as T
 from .scheduler import get_custom_diffusion_scheduler, get_stable_diffusion_scheduler
 
 
@@ -85,8 +86,11 @@ class _EditBase(object):
         bound = self.memory_bound if cap is None else max(1, min(self.memory_bound, cap // per_sample))
         return list(x.split(bound))
 
+    _phase = "U-Net forward (other)"
+
     def _eps(self, x, t, emb=None):
-        out = self.unet(x, t) if emb is None else self.unet(x, t, encoder_hidden_states=emb)
+        with T.phase(self._phase):
+            out = self.unet(x, t) if emb is None else self.unet(x, t, encoder_hidden_states=emb)
         return out if isinstance(out, torch.Tensor) else out.sample
 
     def _basis_paths(self, save_dir, name):
@@ -134,7 +138,8 @@ class EditStableDiffusion(_EditBase):
         self.EXP_NAME = "exp"
 
     def _get_prompt_emb(self, prompt):
-        return self._encode(prompt).to(device=self.device, dtype=torch.float32)
+        with T.phase("prompt encoding (CLIP text model)"):
+            return self._encode(prompt).to(device=self.device, dtype=torch.float32)
 
     @torch.no_grad()
     def run_DDIMforward(self, num_samples=5):
@@ -145,6 +150,7 @@ class EditStableDiffusion(_EditBase):
     @torch.no_grad()
     def run_DDIMinversion(self, idx, guidance=None, vis_traj=False):
         print("start DDIMinversion")
+        self._phase = "DDIM inversion: U-Net forwards"
         self.EXP_NAME = f"DDIMinversion-{self.dataset_name}-{idx}-for_{self.for_prompt}-inv_{self.inv_prompt}"
         do_cfg = (self.guidance_scale > 1.0) & (guidance is not None)
         if not self.use_yh_custom_scheduler:
@@ -173,6 +179,7 @@ class EditStableDiffusion(_EditBase):
     @torch.no_grad()
     def DDIMforwardsteps(self, zt, t_start_idx, t_end_idx, **kwargs):
         print("start DDIMforward")
+        self._phase = "DDIM forward to edit_t: U-Net forwards" if t_end_idx != -1 else "DDIM decode of the edited latents: U-Net forwards"
         do_cfg = self.guidance_scale > 1.0
         if not self.use_yh_custom_scheduler:
             raise ValueError("recommend to use yh custom scheduler")
@@ -197,14 +204,17 @@ class EditStableDiffusion(_EditBase):
                 outs.append(self.scheduler.step(noise_pred, t, lat, eta=0).prev_sample)
             latents = torch.cat(outs, dim=0)
         latents = 1 / 0.18215 * latents
-        x0 = self.vae.decode(latents) if self.vae is not None else latents
-        x0 = (x0 / 2 + 0.5).clamp(0, 1) if self.vae is not None else x0
-        save_image(x0, os.path.join(self.result_folder, f"x0_gen-{self.EXP_NAME}.png"), nrow=x0.size(0))
+        with T.phase("VAE decode"):
+            x0 = self.vae.decode(latents) if self.vae is not None else latents
+            x0 = (x0 / 2 + 0.5).clamp(0, 1) if self.vae is not None else x0
+        with T.phase("image files (PNG encode + write)"):
+            save_image(x0, os.path.join(self.result_folder, f"x0_gen-{self.EXP_NAME}.png"), nrow=x0.size(0))
         return latents
 
     @torch.no_grad()
     def x_space_guidance(self, zt, t_idx, vk, single_edit_step, use_edit_prompt=False):
         t = self.scheduler.timesteps[t_idx]
+        self._phase = "x-space guidance: batch-2 U-Net forwards"
         zt_edit = zt + single_edit_step * vk                                                    # edit.py:490
         et = self._eps(torch.cat([zt, zt_edit], dim=0), t, self.edit_prompt_emb.repeat(2, 1, 1))
         et_null, et_edit = et.chunk(2)
@@ -229,9 +239,10 @@ class EditStableDiffusion(_EditBase):
             vT = torch.load(vT_path, map_location=self.device).type(self.dtype)
         else:
             print("!!!RUN LOCAL PULLBACK!!!")
-            u, s, vT = self.unet.local_encoder_pullback_zt(
-                sample=zt, timestep=t, encoder_hidden_states=self.edit_prompt_emb, op=op, block_idx=block_idx,
-                pca_rank=pca_rank, chunk_size=5, min_iter=10, max_iter=50, convergence_threshold=1e-4)   # edit.py:236-239
+            with T.phase("local_encoder_pullback_zt (power iteration)"):
+                u, s, vT = self.unet.local_encoder_pullback_zt(
+                    sample=zt, timestep=t, encoder_hidden_states=self.edit_prompt_emb, op=op, block_idx=block_idx,
+                    pca_rank=pca_rank, chunk_size=5, min_iter=10, max_iter=50, convergence_threshold=1e-4)   # edit.py:236-239
             vT = vT.to(device=self.device, dtype=self.dtype)
             torch.save(u, u_path); torch.save(s, s_path); torch.save(vT, vT_path)
             save_spectrum_plot(s, os.path.join(save_dir, f"eigenvalue_spectrum-{name}.png"))        # edit.py:249-251

@@ -55,6 +55,7 @@ _FLAGS = [  # (name, type, default) -- define_argparser.py:20-110, live path onl
     # new
     ("pca_rank", int, 2), ("op", str, "mid"), ("block_idx", int, 0), ("vis_num", int, 4), ("vis_num_pc", int, 2), ("weights", str, ""),
     ("net_scale", str, "full"), ("vae", str, "none"), ("text_encoder", str, "none"), ("tokenizer_dir", str, ""),
+    ("timing", str2bool, False),      # wall-clock breakdown of the run by phase (timing.py; synchronises at phase boundaries)
 ]
 
 
@@ -166,11 +167,21 @@ def build_prompt_encoder(args):
 
 
 def main(argv=None):
+    import time
+    from . import timing as T
+    t_start = time.perf_counter()
     args = preset(parse_args(argv))
-    unet = build_unet(args)
+    if getattr(args, "timing", False):
+        T.enable(True)
+    with T.phase("U-Net weights (synthetic draw / load) + engine build + upload"):
+        unet = build_unet(args)
     if args.is_stable_diffusion:
         print("is stable-diffusion")
-        edit = EditStableDiffusion(args, unet=unet, vae=build_vae(args), prompt_encoder=build_prompt_encoder(args))
+        with T.phase("VAE weights + engine build"):
+            vae = build_vae(args)
+        with T.phase("text-encoder weights + engine build"):
+            penc = build_prompt_encoder(args)
+        edit = EditStableDiffusion(args, unet=unet, vae=vae, prompt_encoder=penc)
     else:
         print("is NOT stable-diffusion")
         edit = EditUncondDiffusion(args, unet=unet)
@@ -185,6 +196,8 @@ def main(argv=None):
         edit.run_DDIMforward(num_samples=5)
     if args.run_ddim_inversion:
         edit.run_DDIMinversion(idx=args.sample_idx)
+    if T.ENABLED:
+        print(T.report(time.perf_counter() - t_start))
     return edit
 
 

@@ -136,9 +136,9 @@ def test_graph_replay_of_the_power_iteration_matches_eager_launches():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype):
-    """attn_jvp_shared_kernel / attn_adj_kv_shared_kernel (head dim 40: one block carries all tangents of a sample, P computed once by producer
-    waves) against the per-tangent kernels of round 2 (dpb_debug_set("attn_shared", 0)) on the same inputs: full and ragged tangent groups
-    (k = 5, 4, 7 = 5 + 2, 10), two samples, accumulate flags as the tape sets them.  Both round P / X to 16 bit at slightly different places."""
+    """attn_adj_kv_shared_kernel (head dim 40: one block carries all cotangents of a sample, P computed once by producer waves) against the
+    per-cotangent kernel of round 2 (dpb_debug_set("attn_shared", 0)) on the same inputs: full and ragged cotangent groups (k = 5, 4, 7 = 5 + 2,
+    10), two samples, accumulate flags as the tape sets them.  The two round P / gS to 16 bit at slightly different places."""
     from diffusion_pullback_amd import PullbackUNet
     from diffusion_pullback_amd import lib as L
     from oracle import unet_sd
@@ -157,14 +157,14 @@ def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype):
             V = torch.randn(B * k, 4 * 32 * 32, generator=g)
             U = torch.randn(B * k, e.tap_numel(tap), generator=g)
             out = {}
-            for bits in (0, 3):
+            for bits in (0, 2):
                 L.check(lib.dpb_debug_set(b"attn_shared", bits))
                 e.primal(z[:B], 696.2727, ctx[:B], tap)
                 out[bits] = (e.jvp(tap, V).clone(), e.vjp(tap, U).clone())
-            for a, b in zip(out[0], out[3]):
+            for a, b in zip(out[0], out[2]):
                 assert torch.isfinite(b).all()
                 assert rel(b, a) < tol, (B, k, rel(b, a))
                 for i in range(B * k):                                  # every tangent / cotangent, not just the norm of the stack
                     assert rel(b[i], a[i]) < 2 * tol, (B, k, i, rel(b[i], a[i]))
     finally:
-        L.check(lib.dpb_debug_set(b"attn_shared", 3))
+        L.check(lib.dpb_debug_set(b"attn_shared", 2))

@@ -47,6 +47,7 @@ def main():
     pj = os.path.join(SRC, f"{SRC_TAG}_pmc_mfma.json")
     if os.path.exists(pj):
         agg = {}
+        src_hash = json.load(open(pj)).get("_src_hash", "")
         for k, e in json.load(open(pj))["kernels"].items():
             if "fetch_kb_per_launch" not in e:
                 continue
@@ -62,6 +63,7 @@ def main():
         json.dump({"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 12 --warmup 0 "
                               "--no-cpu-baseline --no-roofline (SD-1.5 mid, k=5, bf16, 1 sample); tools/pmc_mfma.sh",
                    "_units": "KB per launch as reported by rocprofv3; gfx950: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM section)",
+                   "_src_hash": src_hash,      # source hash of the libdpb.so the counters were collected on (bench.py quotes them only for that build)
                    "kernels": kernels}, open(os.path.join(DST, f"{DST_TAG}_pmc_traffic_sd15_mid_k5_bf16.json"), "w"), indent=1)
     print("profiles/:", sorted(f for f in os.listdir(DST) if f.startswith(DST_TAG)))
 

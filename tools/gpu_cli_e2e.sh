@@ -7,7 +7,7 @@ for cfg in "runwayml/stable-diffusion-v1-5 bf16 sd15" "stabilityai/stable-diffus
   rm -rf /tmp/dpb_runs /tmp/inputs; mkdir -p /tmp/dpb_runs       # (the basis cache ./inputs/... is keyed by dataset / steps / rank, not by model -- as in the reference)
   ( cd /tmp && T0=$(date +%s.%N) && python -m diffusion_pullback_amd.main --note demo --model_name $1 --dataset_name Examples --dtype $2 \
       --result_folder /tmp/dpb_runs --edit_prompt "sitting dog" --x_space_guidance_scale 1 --x_space_guidance_num_step 64 --edit_t 0.7 --pca_rank 2 \
-      --run_edit_local_encoder_pullback_zt True --vae synthetic --text_encoder synthetic && python -c "import time,sys; print(\"Elapsed wall seconds:\", round(time.time() - float(sys.argv[1]), 1))" $T0 ) > gpurun_out/${TAG}_main_cli_$3_end_to_end.log 2>&1
+      --run_edit_local_encoder_pullback_zt True --vae synthetic --text_encoder synthetic --timing True && python -c "import time,sys; print(\"Elapsed wall seconds:\", round(time.time() - float(sys.argv[1]), 1))" $T0 ) > gpurun_out/${TAG}_main_cli_$3_end_to_end.log 2>&1
   find /tmp/dpb_runs -name "*.png" | sort >> gpurun_out/${TAG}_main_cli_$3_end_to_end.log
-  grep -E "Elapsed|Error|Traceback|png" gpurun_out/${TAG}_main_cli_$3_end_to_end.log | tail -8
+  grep -E "Elapsed|Error|Traceback|breakdown| s  " gpurun_out/${TAG}_main_cli_$3_end_to_end.log | tail -20
 done

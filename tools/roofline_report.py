@@ -2,6 +2,8 @@
    kernel-trace statistics (time), the two PMC passes (HBM bytes), the per-launch HIP-event CSV (GEMM flops).
 
     python tools/roofline_report.py [profiles] [round-tag] [iterations in the stats run] > profiles/rNN_roofline_report.md
+    python tools/roofline_report.py DIR TAG ITERS CFG PMC_ITERS DTYPE "title"      # any other config (tools/roofline_configs.sh): files
+                                                                                   # DIR/TAG_CFG_kernel_stats.csv, _gemm_launches_hip_events.csv, _pmc.json
 """
 import csv
 import json
@@ -12,7 +14,11 @@ import sys
 DIR = sys.argv[1] if len(sys.argv) > 1 else "profiles"
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
 ITERS = float(sys.argv[3]) if len(sys.argv) > 3 else 48.0        # tools/gpu_session.sh: 12 warm-up + 36 timed iterations
-PEAK_TF, PEAK_HBM = 2500.0, 8.0                                    # bf16 dense MFMA TFLOP/s, HBM TB/s (MI355X_MICROARCH.md)
+CFG = sys.argv[4] if len(sys.argv) > 4 else None                  # None: the headline file names of rounds 1-2
+PMC_ITERS = float(sys.argv[5]) if len(sys.argv) > 5 else 12.0
+DTYPE = sys.argv[6] if len(sys.argv) > 6 else "bf16"
+TITLE = sys.argv[7] if len(sys.argv) > 7 else "SD-1.5 mid-block, k = 5, bf16, one power iteration"
+PEAK_TF, PEAK_HBM = {"fp32": 157.3}.get(DTYPE, 2500.0), 8.0        # dense MFMA TFLOP/s of the dtype, HBM TB/s (MI355X_MICROARCH.md)
 KIND = {"0": "gemm_kernel", "1": "gemm_kernel", "2": "gemm_dma_kernel", "3": "gemm_dma_kernel", "4": "gemm_ring64_kernel", "5": "conv_halo_kernel", "6": "gemm_ring64_kernel"}
 
 
@@ -22,26 +28,33 @@ def family(name):
 
 
 def main():
-    stats = list(csv.DictReader(open(os.path.join(DIR, f"{TAG}_sd15_mid_k5_bf16_kernel_stats.csv"))))
+    n_stats, n_pmc_traffic, n_csv, n_pmc = (f"{TAG}_sd15_mid_k5_bf16_kernel_stats.csv", f"{TAG}_pmc_traffic_sd15_mid_k5_bf16.json",
+                                            f"{TAG}_sd15_gemm_launches_hip_events.csv", f"{TAG}_pmc_sd15_mid_k5_bf16.json")
+    if CFG:
+        n_stats, n_pmc_traffic, n_csv, n_pmc = f"{TAG}_{CFG}_kernel_stats.csv", None, f"{TAG}_{CFG}_gemm_launches_hip_events.csv", f"{TAG}_{CFG}_pmc.json"
+    stats = list(csv.DictReader(open(os.path.join(DIR, n_stats))))
     fam = {}
     for r in stats:
         f = fam.setdefault(family(r["Name"]), [0.0, 0])
         f[0] += float(r["TotalDurationNs"]) / 1e6 / ITERS
         f[1] += int(r["Calls"])
-    pmc = json.load(open(os.path.join(DIR, f"{TAG}_pmc_traffic_sd15_mid_k5_bf16.json")))["kernels"]
+    if n_pmc_traffic:
+        pmc = json.load(open(os.path.join(DIR, n_pmc_traffic)))["kernels"]
+    else:                                                           # per-config runs: FETCH / WRITE sit in the summarize_pmc.py JSON itself
+        pmc = {k: e for k, e in json.load(open(os.path.join(DIR, n_pmc)))["kernels"].items() if "fetch_kb_per_launch" in e}
     hbm = {}                                                        # family -> bytes per iteration
-    pmc_iters = 12.0
+    pmc_iters = PMC_ITERS
     for k, v in pmc.items():
         if " / " in k or v.get("write_kb_per_launch") is None:
             continue
         b = (2.0 * v["fetch_kb_per_launch"] + v["write_kb_per_launch"]) * 1024.0 * v["launches"] / pmc_iters
         hbm[family(k)] = hbm.get(family(k), 0.0) + b
     flops = {}
-    for r in csv.DictReader(open(os.path.join(DIR, f"{TAG}_sd15_gemm_launches_hip_events.csv"))):
+    for r in csv.DictReader(open(os.path.join(DIR, n_csv))):
         f = KIND.get(r["big"], "gemm_kernel")
         flops[f] = flops.get(f, 0.0) + 2.0 * float(r["M"]) * float(r["N"]) * float(r["K"]) * float(r["Z"])
     mfma = {}                                                       # family -> (MFMA busy cycles, SIMD-cycles available) from the SQ pass, if collected
-    pm = os.path.join(DIR, f"{TAG}_pmc_sd15_mid_k5_bf16.json")
+    pm = os.path.join(DIR, n_pmc)
     if os.path.exists(pm):
         for k, e in json.load(open(pm))["kernels"].items():
             raw = e.get("raw", {})
@@ -50,9 +63,10 @@ def main():
                 m[0] += raw.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * e["launches"]
                 m[1] += 1024.0 * raw["GRBM_GUI_ACTIVE"] / 8.0 * e["launches"]
     total = sum(v[0] for v in fam.values())
-    print(f"# Roofline report, SD-1.5 mid-block, k = 5, bf16, one power iteration ({TAG})\n")
+    print(f"# Roofline report, {TITLE} ({TAG})\n")
     print("Sources: `rocprofv3 --kernel-trace --stats` (time), separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (HBM bytes = "
-          "(2·FETCH + WRITE)·1024), per-launch HIP events (GEMM shapes → algorithmic flops). Peaks: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM.")
+          "(2·FETCH + WRITE)·1024), per-launch HIP events (GEMM shapes → algorithmic flops). "
+          f"Peaks: {PEAK_TF:.0f} TFLOP/s dense {DTYPE} MFMA, 8 TB/s HBM.")
     print(f"Kernel time per iteration: **{total:.2f} ms**.\n")
     print("| kernel family | ms / iter | share | launches / iter | algorithmic TFLOP/s | % MFMA peak | MFMA pipe busy (PMC) | HBM GB / iter | HBM TB/s | % HBM peak |")
     print("|---|---|---|---|---|---|---|---|---|---|")

@@ -55,7 +55,13 @@ def main():
             e["hbm_bytes_per_launch"] = (2 * e["fetch_kb_per_launch"] + e["write_kb_per_launch"]) * 1024
         res[k] = e
     order = sorted(res, key=lambda k: -res[k]["gui_active_cycles_per_launch"] * res[k]["launches"])
-    json.dump({"_source": "tools/pmc_mfma.sh (rocprofv3 --pmc ... --kernel-trace, separate passes) on bench.py --steps 12 --warmup 0", "kernels": {k: res[k] for k in order}},
+    src_hash = ""
+    try:                                                            # the library these counters were collected on (bench.py checks it before quoting them)
+        src_hash = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusion_pullback_amd", "libdpb.so.srchash")).read().strip()
+    except OSError:
+        pass
+    json.dump({"_source": "tools/pmc_mfma.sh (rocprofv3 --pmc ... --kernel-trace, separate passes) on bench.py --steps 12 --warmup 0", "_src_hash": src_hash,
+               "kernels": {k: res[k] for k in order}},
               open(os.path.join(SRC, f"{TAG}_pmc_mfma.json"), "w"), indent=1)
     print(f"{'kernel':64s} {'launches':>8s} {'Mcyc tot':>9s} {'MFMA util':>9s} {'wait_inst':>9s} {'wait_any':>9s} {'HBM MB/launch':>13s}")
     for k in order[:40]:
