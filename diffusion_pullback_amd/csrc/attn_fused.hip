@@ -152,6 +152,10 @@ __device__ inline BlockXY xcd_group_blocks(int on) {
   return {slot % nx, (slot / nx) * 8 + xcd};
 }
 
+// shared-P key-major adjoint of the d = 40 layers: bit 1 (A/B switch: DPB_ATTN_SHARED, dpb_debug_set("attn_shared"); bit 0 was the tangent variants)
+static int g_attn_shared = getenv("DPB_ATTN_SHARED") ? atoi(getenv("DPB_ATTN_SHARED")) : 2;
+void attn_debug_shared(int bits) { g_attn_shared = bits; }
+
 #define MFMA(a, b, c) H16<FL>::mfma(a, b, c)   // FL: the enclosing kernel's 16-bit flavour (0 bf16, 1 f16)
 
 struct FusedArgs {
@@ -754,9 +758,12 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(FusedArgs a, int nt) {
 // of stage s; one barrier per stage) and the TJ x 64 row dots D_t = gO_t . O (attn_rowdot_kernel).  Measured 421 -> 326 us per launch (k = 5).
 // Each role runs its OWN copy of the stage loop (same barrier sequence): the producers' look-ahead registers and the consumers' accumulators never
 // share an allocation (one loop for both: 303 spilled VGPRs).
-// (The same construction for the TANGENT kernel -- 2 + 2 TJ tiles per stage: K, V, dK_t, dV_t -- was built and measured in round 3: 420 us single-
-// buffered, 435 us double-buffered against 398 us for attn_jvp_kernel; its per-tangent dK_t / dV_t fragment reads keep the LDS pipe as busy as
-// before while 12-wave barriers add waits (SQ_WAIT_ANY 13 % -> 44 %).  Removed; LDS row paddings of 16 / 24 elements instead of 8: no gain either.)
+// (Sharing P in the TANGENT kernel was built twice in round 3 and removed: (i) this producer / consumer construction with 2 + 2 TJ tiles per stage
+// (K, V, dK_t, dV_t): 420 us single-buffered, 435 us double-buffered against 398 us for attn_jvp_kernel -- the per-tangent dK_t / dV_t fragment
+// reads keep the LDS pipe as busy as before while 12-wave barriers add waits (SQ_WAIT_ANY 13 % -> 44 %); (ii) all TJ tangents in one wave, one
+// 4-wave block per CU like attn_adj_q_multi_kernel (3 + 14 TJ MFMAs per 32 keys, dK_t fragments read one tangent ahead): 256 + 256 registers with
+// 10 spilled, ~530 us -- with one wave per SIMD nothing hides the 7 per-tangent fragment reads per 14 MFMAs.  LDS row paddings of 16 / 24 elements
+// instead of 8: no gain either (9.02 / 9.28 vs 8.99 ms per iteration).)
 template <int D, int TJ> struct SHK {
   static constexpr int QG = 2, NP = QG, NW = NP + QG * TJ, NT = NW * 64;
   static constexpr int BI = 64;                                     // queries per LDS stage (two 32-query blocks); the stage ring is double-buffered
@@ -1154,10 +1161,6 @@ int launch_row_stats(int fl, const void* S, float* stats, long nrows, int Lk, in
   DPB_CHECK(hipGetLastError());
   return 0;
 }
-
-// shared-P key-major adjoint of the d = 40 layers: bit 1 (A/B switch: DPB_ATTN_SHARED, dpb_debug_set("attn_shared"); bit 0 was the tangent variant)
-static int g_attn_shared = getenv("DPB_ATTN_SHARED") ? atoi(getenv("DPB_ATTN_SHARED")) : 2;
-void attn_debug_shared(int bits) { g_attn_shared = bits; }
 
 static int attn_xcd_on() { static int on = getenv("DPB_ATTN_XCD") ? atoi(getenv("DPB_ATTN_XCD")) : 0; return on; }
 

@@ -83,6 +83,9 @@ struct dpb_engine {
   size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
   size_t temb_host_stage = 0;
   int cur_batch = 0;
+  std::vector<int> uses;            // buffer -> number of ops reading it (in0 / in1 / in2 / res)
+  int cur_tap = -1;                 // tap buffer of the pass being run
+  struct { bool on = false; GemmArgs a; } pend;   // a split-K product whose reduction is deferred to the normalisation op that consumes it
   bool fwd_only = false;            // dpb_forward: primal pass that keeps no tangent / adjoint stash (DDIM loop)
   std::vector<char> ginit;
   std::vector<char> skip;           // ops whose work a fused epilogue of another op has done in the current pass
@@ -123,13 +126,25 @@ void gemm_prep(dpb_engine* e, GemmArgs& a) {
   a.slab_bytes = e->slab_bytes;
 }
 
-int gemm(dpb_engine* e, GemmArgs a) {
+// split-K products whose consumer is a GroupNorm (one-launch kernel) / LayerNorm leave their slabs to it (A/B switch: DPB_LAZY_REDUCE=0,
+// dpb_debug_set("lazy_reduce", 0): every split-K product runs its own reduce kernel; the results are bitwise the same)
+int g_lazy_reduce = getenv("DPB_LAZY_REDUCE") ? atoi(getenv("DPB_LAZY_REDUCE")) : 1;
+
+int flush_pending(dpb_engine* e) {                 // the designated consumer did not come next: reduce the parked product the ordinary way
+  if (!e->pend.on) return 0;
+  e->pend.on = false;
+  e->n_launch++;
+  return launch_gemm_reduce(e->dtype, e->pend.a, e->stream);
+}
+
+int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false) {
   gemm_prep(e, a);
+  GemmArgs* pend = (can_defer && g_lazy_reduce) ? &e->pend.a : nullptr;
   const double kk = (double)a.K + (a.A2 ? a.K2 : 0);
   e->flops += 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
   int nl = 1;                                   // kernels enqueued: the product itself (+ splitk_reduce_kernel for split-K launches)
-  if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl); e->n_launch += nl; return r; }
+  if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl, pend); e->n_launch += nl; e->pend.on = pend && pend->splitk > 1; return r; }
   dpb_engine::Prof p;
   p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile
@@ -137,8 +152,9 @@ int gemm(dpb_engine* e, GemmArgs a) {
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));
   DPB_CHECK(hipEventRecord(p.a, e->stream));
-  int r = launch_gemm(e->dtype, a, e->stream, &nl);
+  int r = launch_gemm(e->dtype, a, e->stream, &nl, pend);
   e->n_launch += nl;
+  e->pend.on = pend && pend->splitk > 1;
   DPB_CHECK(hipEventRecord(p.b, e->stream));
   e->prof.push_back(p);
   return r;
@@ -196,7 +212,7 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
       return gemm(e, f);
     }
   }
-  return gemm(e, g);
+  return gemm(e, g, mode == 1 && !shared_out);      // tangent: a following GroupNorm / LayerNorm may add the split-K slabs itself
 }
 
 int conv_adj(dpb_engine* e, const Op& op, int n) {
@@ -229,18 +245,19 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
         goto residual;
       }
     }
+    const bool lone = e->uses[d.in0] == 1 && d.in0 != e->x_buf;   // the cotangent has this one contribution: its producer's adjoint may add the slabs
     if (gather == GATHER_NONE) {
       g.M = n * bi.rows;
       g.C = e->G(d.in0);
       g.accumulate = e->ginit[d.in0];
-      if (int r = gemm(e, g)) return r;
+      if (int r = gemm(e, g, lone)) return r;
     } else if (gather == GATHER_CONV) {
       g.gather = GATHER_CONVT;
       g.M = n * H * W;
       g.H = Ho; g.W = Wo; g.Cin = Cout; g.Ho = H; g.Wo = W; g.KS = KS; g.stride = d.ip[7]; g.pad = d.ip[8];
       g.C = e->G(d.in0);
       g.accumulate = e->ginit[d.in0];
-      if (int r = gemm(e, g)) return r;
+      if (int r = gemm(e, g, lone)) return r;
     } else {   // UPCONV: adjoint conv at the upsampled resolution, then 2x2 sum pooling
       g.gather = GATHER_CONVT;
       g.M = n * Ho * Wo;
@@ -269,6 +286,31 @@ residual:
 }
 
 // ------------------------------------------------------------------ norms / elementwise
+// The normalisation op about to run reads `d`: if that is the output of the parked split-K product, hand it the slabs (run_op has already made
+// sure that nothing else is parked).  `store`: the reduced tensor has other readers (residual stream, tap) and must be written as well.
+void take_pending(dpb_engine* e, SlabSrc& src, const void* d, bool store) {
+  if (!e->pend.on || e->pend.a.C != d) return;
+  const GemmArgs& g = e->pend.a;
+  src.slab = g.slab; src.splitk = g.splitk; src.MN = (long)g.M * g.N; src.N = g.N;
+  src.R = g.R; src.ldr = g.ldr;
+  src.store = store ? g.C : nullptr;
+  e->pend.on = false;
+}
+
+// does `op`, about to run in `mode`, consume the parked product itself?  (GroupNorm: only the one-launch kernel takes slabs.)
+bool consumes_pending(dpb_engine* e, const Op& op, int mode) {
+  if (mode == MODE_PRIMAL || (op.d.kind != DPB_OP_GROUPNORM && op.d.kind != DPB_OP_LAYERNORM)) return false;
+  const void* d = mode == MODE_TANGENT ? (const void*)e->T(op.d.in0) : (const void*)e->G(op.d.out);
+  if (d != e->pend.a.C) return false;
+  const Buf& bi = e->bufs[op.d.in0];
+  if (e->pend.a.N != bi.C) return false;
+  if (op.d.kind == DPB_OP_GROUPNORM) {
+    GNArgs a; a.HW = bi.rows; a.C = bi.C; a.G = op.d.ip[0]; a.NT = 1;
+    return groupnorm_launches(e->dtype, mode, a) == 1;
+  }
+  return true;
+}
+
 int gn_run(dpb_engine* e, const Op& op, int mode, int n) {
   const dpb_op_desc& d = op.d;
   const Buf& bi = e->bufs[d.in0];
@@ -297,6 +339,7 @@ int gn_run(dpb_engine* e, const Op& op, int mode, int n) {
       a.accumulate = e->ginit[d.in0];
       e->ginit[d.in0] = 1;
     }
+    take_pending(e, a.src, a.d, mode == MODE_TANGENT && (e->uses[d.in0] > 1 || d.in0 == e->cur_tap));
   }
   e->n_launch += groupnorm_launches(e->dtype, mode, a);
   return launch_groupnorm(e->dtype, mode, a, e->stream);
@@ -326,6 +369,7 @@ int ln_run(dpb_engine* e, const Op& op, int mode, int n) {
       a.accumulate = e->ginit[d.in0];
       e->ginit[d.in0] = 1;
     }
+    take_pending(e, a.src, a.d, mode == MODE_TANGENT && (e->uses[d.in0] > 1 || d.in0 == e->cur_tap));
   }
   e->n_launch++;
   return launch_layernorm(e->dtype, mode, a, e->stream);
@@ -594,6 +638,8 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
 }
 
 int run_op(dpb_engine* e, const Op& op, int mode, int n) {
+  if (e->pend.on && !consumes_pending(e, op, mode))
+    if (int r = flush_pending(e)) return r;
   switch (op.d.kind) {
     case DPB_OP_CONV: return mode == MODE_ADJOINT ? conv_adj(e, op, n) : conv_fwd(e, op, mode, n);
     case DPB_OP_GROUPNORM: return gn_run(e, op, mode, n);
@@ -708,6 +754,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       const dpb_op_desc& d = e->ops[i].d;
       for (int b : {d.in0, d.in1, d.in2, d.res}) if (b >= 0 && b < nb) { uses[b]++; user[b] = (int)i; }
     }
+    e->uses = uses;
     for (size_t j = 0; j < e->ops.size(); ++j) {
       const dpb_op_desc& d = e->ops[j].d;
       // the primal GEGLU overwrites its input by the factors (G1, G2) (elementwise.hip): nothing else may read that buffer
@@ -907,10 +954,12 @@ int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
   if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));   // atomic statistics accumulate
   const int last = e->producer[tap];
   std::fill(e->skip.begin(), e->skip.end(), 0);
+  e->cur_tap = tap; e->pend.on = false;
   for (int i = 0; i <= last; ++i) {
     if (e->ops[i].is_const || e->skip[i]) continue;
     if (int r = run_op(e, e->ops[i], MODE_TANGENT, nt)) return r;
   }
+  if (int r = flush_pending(e)) return r;
   const Buf& bt = e->bufs[tap];
   e->n_launch++;
   return launch_nhwc_to_nchw(e->dtype, e->T(tap), U, nt, bt.Cv, bt.rows, bt.C, e->stream);
@@ -927,11 +976,13 @@ int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
   e->ginit[tap] = 1;
   if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
+  e->cur_tap = tap; e->pend.on = false;
   for (int i = e->producer[tap]; i >= 0; --i) {
     const Op& op = e->ops[i];
     if (op.is_const || !e->ginit[op.d.out]) continue;
     if (int r = run_op(e, op, MODE_ADJOINT, nt)) return r;
   }
+  if (int r = flush_pending(e)) return r;
   if (!e->ginit[e->x_buf]) return fail("tap buffer %d is not connected to x", tap);
   const Buf& bx = e->bufs[e->x_buf];
   e->n_launch++;
@@ -1095,6 +1146,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gn_deterministic")) { gn_debug_deterministic(value); return 0; }
   else if (!strcmp(key, "graph_iterate")) { g_graph_iterate = value; return 0; }
   else if (!strcmp(key, "attn_shared")) { attn_debug_shared(value); return 0; }
+  else if (!strcmp(key, "lazy_reduce")) { g_lazy_reduce = value; return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

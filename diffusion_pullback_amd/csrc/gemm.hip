@@ -446,6 +446,7 @@ void gemm_debug_order(int o) { g_force_order = o; }
 void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 static thread_local int t_reduce_launched = 0;   // set by launch_t when a splitk_reduce_kernel launch followed the product
+static thread_local GemmArgs* t_pending = nullptr;   // launch_gemm(..., pending): where a deferrable reduction is parked instead of launched
 
 int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
   // Register-staged kernel, measured on MI355X (tools/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt):
@@ -700,19 +701,35 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
     else launch_reg_t<T, 64, 64, 4>(a, grid, st);
   }
   if (a.splitk > 1) {
-    long total = (long)a.M * a.N * Z / 4;
-    unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
-    t_reduce_launched = 1;
+    const bool plain = Z == 1 && a.alpha == 1.f && !a.bias && !a.rowbias && !a.accumulate && a.ldc == a.N && a.vec_ok && !(a.N & 7) && a.epi == EPI_PLAIN;
+    if (t_pending && plain) {
+      *t_pending = a;                               // the consumer (or launch_gemm_reduce) adds the slabs
+    } else {
+      long total = (long)a.M * a.N * Z / 4;
+      unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a);
+      t_reduce_launched = 1;
+    }
   }
   DPB_CHECK(hipGetLastError());
   return 0;
 }
 
-int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches) {
+int launch_gemm_reduce(int dtype, const GemmArgs& a, hipStream_t st) {
+  if (a.splitk <= 1) return 0;
+  const long total = (long)a.M * a.N * a.Z1 * a.Z2 / 4;
+  const unsigned g = (unsigned)std::max<long>(1, std::min<long>((total + 255) / 256, 4096));
+  DPB_DISPATCH_STMT(dtype, T, hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, st, a));
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches, GemmArgs* pending) {
   GemmArgs b = a;
   b.fl = dtype == DT_F16;           // 16-bit flavour of the specialised kernels (H16<fl>)
   t_reduce_launched = 0;
+  if (pending) pending->splitk = 1;
+  t_pending = pending;
   static const int trace = getenv("DPB_GEMM_TRACE") ? atoi(getenv("DPB_GEMM_TRACE")) : 0;   // debugging: print every product, synchronise after it
   if (trace) {
     fprintf(stderr, "gemm M=%d N=%d K=%d Z=%d gather=%d epi=%d lda=%d ldb=%d ldc=%d ldr=%d acc=%d R=%d bias=%d rowbias=%d kind=%d\n", b.M, b.N, b.K, b.Z1 * b.Z2, b.gather,
@@ -721,6 +738,7 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches) {
   }
   const int r = DPB_DISPATCH_T(dtype, T, launch_t<T>(dtype, b, st));
   if (trace && hipStreamSynchronize(st) != hipSuccess) fprintf(stderr, "gemm: the launch above failed\n");
+  t_pending = nullptr;
   if (launches) *launches = 1 + t_reduce_launched;
   return r;
 }

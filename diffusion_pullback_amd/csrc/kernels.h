@@ -42,7 +42,12 @@ struct GemmArgs {
   int fl = 0;                         // 16-bit flavour of the specialised kernels: 0 bf16, 1 f16 (filled in by launch_gemm)
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
-int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches = nullptr);   // *launches: kernels enqueued (1, or 2 with splitk_reduce_kernel)
+// *launches: kernels enqueued (1, or 2 with splitk_reduce_kernel).  `pending` != nullptr: if the launch is split over K and its epilogue is plain
+// (one batch entry, alpha 1, no bias / row bias / accumulate, dense rows), the reduce kernel is NOT launched -- *pending receives the prepared
+// arguments (pending->splitk > 1) and the caller either hands the slabs to a consumer that reduces them itself (SlabSrc, norm.hip) or calls
+// launch_gemm_reduce; otherwise pending->splitk is set to 1.
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches = nullptr, GemmArgs* pending = nullptr);
+int launch_gemm_reduce(int dtype, const GemmArgs& pending, hipStream_t st);
 struct GemmPlan { int kind, tile, splitk; };   // kind: 0 / 1 register-staged 64x64 / 128x128, 2 LDS ring (tile = its code), 3 halo-tile convolution; -1 error
 GemmPlan gemm_plan(int dtype, const GemmArgs& a);   // host-only: the kernel launch_gemm picks, with its K split (clamped to the slab scratch)
 int gemm_uses_big_tile(int dtype, const GemmArgs& a);
@@ -63,6 +68,14 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile);   // tuning overrides for
 
 // ---------------------------------------------------------------- normalisation
 enum { MODE_PRIMAL = 0, MODE_TANGENT = 1, MODE_ADJOINT = 2 };
+// A deferred split-K reduction handed to the normalisation kernel that consumes the product: its tangent / cotangent input d[row][c..] is
+// sum_s slab[s][row][c..] (+ R[row][c..]), added in slab order and rounded to the engine dtype exactly as splitk_reduce_kernel would have
+// stored it (bitwise the same values), optionally written to `store` when another op reads the buffer too.
+struct SlabSrc {
+  const float* slab = nullptr; int splitk = 0; long MN = 0; int N = 0;
+  const void* R = nullptr; int ldr = 0;
+  void* store = nullptr;
+};
 struct GNArgs {
   const void* x = nullptr;        // primal input  [Bp][HW][C]
   const void* d = nullptr;        // tangent dx or cotangent gz [NT][HW][C] (modes 1,2)
@@ -79,6 +92,7 @@ struct GNArgs {
   int HW = 0, C = 0, G = 32;
   float eps = 1e-5f;
   int silu = 0, accumulate = 0;
+  SlabSrc src;                    // tangent / adjoint, one-launch kernel only: d comes from split-K slabs
 };
 int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st);
 int groupnorm_launches(int dtype, int mode, const GNArgs& a);
@@ -89,6 +103,7 @@ struct LNArgs {
   int rows_per_sample = 0, Bp = 1, NT = 0, kps = 1, C = 0;
   float eps = 1e-5f;
   int accumulate = 0;
+  SlabSrc src;                    // tangent / adjoint: d comes from split-K slabs
 };
 int launch_layernorm(int dtype, int mode, const LNArgs& a, hipStream_t st);
 

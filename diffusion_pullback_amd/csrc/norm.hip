@@ -21,6 +21,57 @@ static int g_gn_det = getenv("DPB_GN_DETERMINISTIC") ? atoi(getenv("DPB_GN_DETER
 void gn_debug_deterministic(int on) { g_gn_det = on; }
 int gn_deterministic() { return g_gn_det; }
 
+
+// d[row][c0 .. c0 + CH) of a deferred split-K reduction (SlabSrc): slabs added in slab order, + residual, rounded to T like the reduce kernel's
+// store (the caller continues with exactly the values the separate reduce + load would have given); optional store for other readers.
+template <typename T>
+__device__ inline uint4 slab_chunk(const SlabSrc& s, long row, int c0) {
+  constexpr int CH = TT<T>::CH;
+  float v[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) v[e] = 0.f;
+  const float* sp = s.slab + row * s.N + c0;
+  auto ld = [&](int k, float* t) {
+    Vec<float>::load(sp + (long)k * s.MN, t);
+    if constexpr (CH == 8) Vec<float>::load(sp + (long)k * s.MN + 4, t + 4);
+  };
+  int k = 0;
+  for (; k + 8 <= s.splitk; k += 8) {               // eight, then four slabs in flight; always added in slab order
+    float t[8][CH];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ld(k + u, t[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += t[u][e];
+  }
+  if (k + 4 <= s.splitk) {
+    float t[4][CH];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ld(k + u, t[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += t[u][e];
+    k += 4;
+  }
+  for (; k < s.splitk; ++k) {
+    float t[CH];
+    ld(k, t);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) v[e] += t[e];
+  }
+  if (s.R) {
+    float r[CH];
+    Vec<T>::load((const T*)s.R + row * s.ldr + c0, r);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) v[e] += r[e];
+  }
+  const uint4 packed = Raw<T>::pack(v);
+  if (s.store) *reinterpret_cast<uint4*>((T*)s.store + row * s.N + c0) = packed;
+  return packed;
+}
+
 template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
   constexpr int CH = TT<T>::CH;
@@ -55,7 +106,9 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
       for (int bb = b0; bb < b1; bb += 32) {            // 32 independent L2-resident loads in flight, then added in block order
         float v[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = bb + u < b1 ? pj[(long)(bb + u) * n2 + i] : 0.f;
+        for (int u = 0; u < 32; ++u) v[u] = pj[(long)min(bb + u, b1 - 1) * n2 + i];      // (clamped, not predicated: predicated loads compile to
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = bb + u < b1 ? v[u] : 0.f;                     //  a branch and a full s_waitcnt per load)
 #pragma unroll
         for (int u = 0; u < 32; ++u) acc += (double)v[u];
       }
@@ -278,7 +331,7 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(GNArgs a, int GC) {
     const int p = pr + i * ppi;
     if (active && p < a.HW) {
       xr[i] = *reinterpret_cast<const uint4*>((const T*)a.x + ((long)b * a.HW + p) * a.C + ch0);
-      if (MODE != MODE_PRIMAL) dr[i] = *reinterpret_cast<const uint4*>((const T*)a.d + ((long)j * a.HW + p) * a.C + ch0);
+      if (MODE != MODE_PRIMAL) dr[i] = a.src.slab ? slab_chunk<T>(a.src, (long)j * a.HW + p, ch0) : *reinterpret_cast<const uint4*>((const T*)a.d + ((long)j * a.HW + p) * a.C + ch0);
     }
   }
 #pragma unroll
@@ -467,6 +520,7 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
     DPB_CHECK(hipGetLastError());
     return 0;
   }
+  if (a.src.slab) { set_error("groupnorm: split-K slab input is taken by the one-launch kernel only"); return -1; }
   int ppb = 64;
   static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;   // tuning override
   while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
@@ -532,7 +586,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {   // th
     int c = lane + i * 64;
     if (c < nch) {
       Vec<T>::load(xp + c * CH, x[i]);
-      if (MODE != MODE_PRIMAL) Vec<T>::load((const T*)a.d + row * a.C + c * CH, v[i]);   // issued with x: both in flight across the reductions
+      if (MODE != MODE_PRIMAL) {                                                          // issued with x: both in flight across the reductions
+        if (a.src.slab) Raw<T>::unpack(slab_chunk<T>(a.src, row, c * CH), v[i]);
+        else Vec<T>::load((const T*)a.d + row * a.C + c * CH, v[i]);
+      }
 #pragma unroll
       for (int e = 0; e < CH; ++e) s += x[i][e];
     }
@@ -632,7 +689,10 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(LNArgs a, long nrows) {
   for (int i = 0; i < NI; ++i) {
     const int c = l + i * LPR;
     Vec<T>::load(xp + c * CH, x[i]);
-    if (MODE != MODE_PRIMAL) Vec<T>::load((const T*)a.d + r * a.C + c * CH, v[i]);
+    if (MODE != MODE_PRIMAL) {
+      if (a.src.slab) { if (live) Raw<T>::unpack(slab_chunk<T>(a.src, r, c * CH), v[i]); else for (int e = 0; e < CH; ++e) v[i][e] = 0.f; }
+      else Vec<T>::load((const T*)a.d + r * a.C + c * CH, v[i]);
+    }
 #pragma unroll
     for (int e = 0; e < CH; ++e) s += x[i][e];
   }

@@ -168,3 +168,40 @@ def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype):
                     assert rel(b[i], a[i]) < 2 * tol, (B, k, i, rel(b[i], a[i]))
     finally:
         L.check(lib.dpb_debug_set(b"attn_shared", 2))
+
+
+def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
+    """Split-K products whose consumer is a one-launch GroupNorm or a LayerNorm leave their fp32 slabs to that kernel (no splitk_reduce_kernel launch,
+    no 16-bit round trip of the tensor unless another op reads it).  The consumer adds the slabs in slab order, adds the residual and rounds exactly
+    like the reduce kernel: tangent and adjoint passes at full SD-1.5 width (8x8 / 16x16 levels: every split-K shape of the headline) are bitwise
+    identical with dpb_debug_set("lazy_reduce", 0 | 1), and fewer kernels are launched."""
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    from diffusion_pullback_amd import lib as L
+    lib = L.load()
+    enc = ("time_embedding", "conv_in", "down_blocks", "mid_block")
+    params = cf.sd_init_params(cf.SD15, seed=0, only_prefix=enc, spectrum=cf.Spectrum())
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randn(2, 77, 768, generator=g); z = torch.randn(2, 4, 64, 64, generator=g)
+    tap = ("mid", 0)
+    for dtype in (torch.bfloat16, torch.float32):
+        net = PullbackUNet("sd", cf.SD15, params, dtype=dtype, device="cuda:0", max_batch=2, max_rank=10, upto=tap, verbose=False)
+        e = net.engine
+        for B, k in [(1, 5), (2, 5), (1, 1)]:
+            V = torch.randn(B * k, 16384, generator=g)
+            U = torch.randn(B * k, e.tap_numel(tap), generator=g)
+            out, launches = {}, {}
+            try:
+                for lazy in (0, 1):
+                    L.check(lib.dpb_debug_set(b"lazy_reduce", lazy))
+                    e.primal(z[:B], 696.2727, ctx[:B], tap)
+                    jv = e.jvp(tap, V).clone(); lj = e.stats()[0]
+                    vj = e.vjp(tap, U).clone(); lv = e.stats()[0]
+                    out[lazy], launches[lazy] = (jv, vj), (lj, lv)
+            finally:
+                L.check(lib.dpb_debug_set(b"lazy_reduce", 1))
+            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), (dtype, B, k)
+            print(dtype, B, k, "launches (jvp, vjp): separate reduce", launches[0], "deferred", launches[1])
+            if dtype == torch.bfloat16 and k == 5:
+                assert launches[1][0] < launches[0][0] and launches[1][1] < launches[0][1]
+        del net
+        torch.cuda.empty_cache()
