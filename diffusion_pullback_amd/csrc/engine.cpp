@@ -59,6 +59,8 @@ struct Op {
   size_t pstats = 0, tstats = 0;   // GroupNorm stat slots (offsets)
   int geglu_next = -1;       // CONV (FF-in): the GEGLU op that is the only consumer of its output (interleaved layout) -> fused tangent epilogue
   int geglu_prev = -1;       // CONV (FF-out): the GEGLU op that produces its input                                   -> fused adjoint epilogue
+  int ln_next = -1;          // CONV: the LayerNorm op that reads its 320-wide output  -> tangent: product + LayerNorm tangent in one launch (EPI_LN_TAN)
+  int ln_prev = -1;          // CONV: the LayerNorm op whose output is its only input -> adjoint: product + LayerNorm adjoint in one launch (EPI_LN_ADJ)
 };
 
 }  // namespace dpb
@@ -129,6 +131,8 @@ void gemm_prep(dpb_engine* e, GemmArgs& a) {
 // split-K products whose consumer is a GroupNorm (one-launch kernel) / LayerNorm leave their slabs to it (A/B switch: DPB_LAZY_REDUCE=0,
 // dpb_debug_set("lazy_reduce", 0): every split-K product runs its own reduce kernel; the results are bitwise the same)
 int g_lazy_reduce = getenv("DPB_LAZY_REDUCE") ? atoi(getenv("DPB_LAZY_REDUCE")) : 1;
+// LayerNorm tangent / adjoint in the epilogue of the neighbouring 320-wide product (A/B switch: DPB_LN_FUSE=0, dpb_debug_set("ln_fuse", 0))
+int g_ln_fuse = getenv("DPB_LN_FUSE") ? atoi(getenv("DPB_LN_FUSE")) : 1;
 
 int flush_pending(dpb_engine* e) {                 // the designated consumer did not come next: reduce the parked product the ordinary way
   if (!e->pend.on) return 0;
@@ -201,6 +205,17 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
     g.R = mode == 0 ? e->P(d.res) : e->T(d.res);
     g.ldr = e->bufs[d.res].C;
   }
+  if (mode == 1 && op.ln_next >= 0 && g_ln_fuse) {   // the LayerNorm that reads this product's output: its tangent leaves the same launch
+    const dpb_op_desc& ld = e->ops[op.ln_next].d;
+    GemmArgs f = g;
+    f.epi = EPI_LN_TAN; f.C2 = e->T(ld.out); f.ln_x = e->P(ld.in0); f.ln_gamma = (const float*)ld.w[0]; f.ln_eps = ld.fp[0];
+    f.rows_per_sample = bo.rows; f.epi_kps = n / e->cur_batch;
+    gemm_prep(e, f);
+    if (gemm_epi_supported(e->dtype, f)) {
+      e->skip[op.ln_next] = 1;
+      return gemm(e, f);
+    }
+  }
   if (mode == 1 && op.geglu_next >= 0) {   // FF-in tangent: GEGLU's tangent in the epilogue, dh [rows][2F] is never written
     const dpb_op_desc& gd = e->ops[op.geglu_next].d;
     GemmArgs f = g;
@@ -232,6 +247,22 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
     g.ldb = g.K;
     g.ldc = bi.C;
     const int gather = d.ip[9];
+    // the LayerNorm that wrote this product's input: its adjoint in the epilogue (K <= 1024: beyond -- the FF-in adjoint, K = 8 C -- the
+    // row-complete tile's one block per CU loses more in the K loop than the fusion saves: g_ln_fuse bit 1 forces it for A/Bs)
+    if (gather == GATHER_NONE && op.ln_prev >= 0 && g_ln_fuse && e->uses[d.in0] == 1 && (g.K <= 1024 || (g_ln_fuse & 2))) {
+      const dpb_op_desc& ld = e->ops[op.ln_prev].d;
+      GemmArgs f = g;
+      f.M = n * bi.rows;
+      f.epi = EPI_LN_ADJ; f.C = e->G(ld.in0); f.ldc = e->bufs[ld.in0].C; f.accumulate = e->ginit[ld.in0];
+      f.ln_x = e->P(ld.in0); f.ln_gamma = (const float*)ld.w[0]; f.ln_eps = ld.fp[0];
+      f.rows_per_sample = bi.rows; f.epi_kps = n / e->cur_batch;
+      gemm_prep(e, f);
+      if (gemm_epi_supported(e->dtype, f)) {
+        if (int r = gemm(e, f)) return r;
+        e->ginit[ld.in0] = 1;               // G(d.in0) stays unwritten: the LayerNorm op sees ginit == 0 and is skipped
+        goto residual;
+      }
+    }
     if (gather == GATHER_NONE && op.geglu_prev >= 0) {   // FF-out adjoint: GEGLU's adjoint in the epilogue, gy [rows][F] is never written
       const dpb_op_desc& gd = e->ops[op.geglu_prev].d;
       GemmArgs f = g;
@@ -755,6 +786,20 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       for (int b : {d.in0, d.in1, d.in2, d.res}) if (b >= 0 && b < nb) { uses[b]++; user[b] = (int)i; }
     }
     e->uses = uses;
+    // LayerNorm fused into the neighbouring product's epilogue (row-complete 128 x 320 ring tile, 16-bit engines): tangent -- the product that
+    // WRITES the LayerNorm input also writes the LayerNorm tangent; adjoint -- the adjoint of the product that READS the LayerNorm output
+    // applies the LayerNorm adjoint to its result.  (The 64 x 64 level of SD: C = 320.)
+    for (size_t j = 0; j < e->ops.size(); ++j) {
+      const dpb_op_desc& d = e->ops[j].d;
+      if (d.kind != DPB_OP_LAYERNORM || e->ops[j].is_const || e->dtype == DT_F32 || e->bufs[d.in0].C != 320 || e->bufs[d.in0].kind != DPB_BUF_ACT) continue;
+      const int pi = e->producer[d.in0];
+      if (pi >= 0 && e->ops[pi].d.kind == DPB_OP_CONV && e->ops[pi].d.ip[9] == DPB_GATHER_NONE && !e->ops[pi].is_const) e->ops[pi].ln_next = (int)j;
+      if (uses[d.out] == 1) {
+        const int ci = user[d.out];
+        const dpb_op_desc& cd = e->ops[ci].d;
+        if (cd.kind == DPB_OP_CONV && cd.ip[9] == DPB_GATHER_NONE && cd.in0 == d.out && cd.w[1]) e->ops[ci].ln_prev = (int)j;
+      }
+    }
     for (size_t j = 0; j < e->ops.size(); ++j) {
       const dpb_op_desc& d = e->ops[j].d;
       // the primal GEGLU overwrites its input by the factors (G1, G2) (elementwise.hip): nothing else may read that buffer
@@ -1147,6 +1192,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "graph_iterate")) { g_graph_iterate = value; return 0; }
   else if (!strcmp(key, "attn_shared")) { attn_debug_shared(value); return 0; }
   else if (!strcmp(key, "lazy_reduce")) { g_lazy_reduce = value; return 0; }
+  else if (!strcmp(key, "ln_fuse")) { g_ln_fuse = value; return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

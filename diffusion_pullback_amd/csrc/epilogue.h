@@ -9,10 +9,120 @@
 //                  dy = da*G1 + dg*G2 [M][F] -- dh [M][2F] never exists in HBM, and no transcendental runs in the epilogue.
 //   EPI_GEGLU_ADJ  adjoint of GEGLU fused into the adjoint of the FF-out product: the tile holds gy for 128 hidden units; writes
 //                  ga = gy*G1 and gg = gy*G2 at their interleaved positions of gh [M][2F].
+//   EPI_LN_TAN     (row-complete tile: BN = N, epilogue_ln below) h = acc (+R) -> C, and the LayerNorm tangent of h at the primal row -> C2
+//   EPI_LN_ADJ     (row-complete tile) the LayerNorm adjoint of acc (= cotangent of the LayerNorm output) (+)-> C
 #pragma once
 #include "kernels.h"
 
 namespace dpb {
+
+// Row-complete tiles (the block holds whole rows of the product: BN = N, two waves side by side).  64 rows of fp32 accumulators are staged as
+// [wave][32][SLD] (waves 2 wy, 2 wy + 1 hold the two halves of the same 32 rows); each wave then owns 16 of the 64 rows, EIGHT rows at a time:
+// 8 lanes per row, lane l of a row holds the 16-byte chunks l, l + 8, ... (N / 64 of them), so the row reductions are 3-step shuffles inside
+// 8-lane groups (one row per wave with 6-step ds_bpermute reductions, 4 dependent ones per row, cost 35 us per launch: latency-bound with one
+// wave per SIMD).  LayerNorm algebra as in norm.hip (ln_rows_kernel):
+//   tangent:  z = gamma o rstd (v - mean(v) - xhat mean(xhat v)),            v = h = acc + R (rounded to 16 bit like the stored h)
+//   adjoint:  g = rstd (w - mean(w) - xhat mean(xhat w)),  w = gamma o gz,   gz = acc (rounded to 16 bit like a stored cotangent)
+__device__ inline float seg8_sum(float v) {
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+template <int WN> struct LnPre { uint4 xr[2][2 * WN / 64], rres[2][2 * WN / 64]; };   // primal rows and residual / accumulated rows of one 64-row step
+// issued at kernel start (the addresses do not depend on the product): the loads land under the K loop instead of in front of the epilogue
+template <int FL, int WN, int EPI>
+__device__ __forceinline__ void ln_prefetch(const GemmArgs& p, const bf16* C, const bf16* R, int wave, int lane, int mrow0_block, LnPre<WN>& q) {
+  constexpr int NI = 2 * WN / 64;
+  const int wy = wave >> 1, rg = lane >> 3, l = lane & 7;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int m = min(mrow0_block + wy * 32 + (wave & 1) * 16 + ps * 8 + rg, p.M - 1);
+    const int smp = m / p.rows_per_sample, lr = m - smp * p.rows_per_sample;
+    const long prow = (long)(smp / p.epi_kps) * p.rows_per_sample + lr;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = (l + 8 * i) * 8;
+      q.xr[ps][i] = *reinterpret_cast<const uint4*>((const bf16*)p.ln_x + prow * p.N + n);
+      q.rres[ps][i] = make_uint4(0, 0, 0, 0);
+      if (EPI == EPI_LN_TAN && R) q.rres[ps][i] = *reinterpret_cast<const uint4*>(R + (long)m * p.ldr + n);
+      if (EPI == EPI_LN_ADJ && p.accumulate) q.rres[ps][i] = *reinterpret_cast<const uint4*>(C + (long)m * p.ldc + n);   // the cotangent accumulated so far
+    }
+  }
+}
+
+template <int FL, int WN, int SLD, int EPI>
+__device__ __forceinline__ void epilogue_ln(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0_block, const LnPre<WN>& q) {
+  constexpr int NI = 2 * WN / 64;                                // chunks per lane: N / 8 chunks over 8 lanes
+  static_assert(2 * WN % 64 == 0, "N = 2 WN must be a multiple of 64");
+  const int wy = wave >> 1, rg = lane >> 3, l = lane & 7;
+  const float inv_c = 1.f / (float)p.N;
+  float gam[NI][8];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { Vec<float>::load(p.ln_gamma + (l + 8 * i) * 8, gam[i]); Vec<float>::load(p.ln_gamma + (l + 8 * i) * 8 + 4, gam[i] + 4); }
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int row = (wave & 1) * 16 + ps * 8 + rg;               // of the 32 rows staged by the wave pair (2 wy, 2 wy + 1)
+    const int m = mrow0_block + wy * 32 + row;
+    const bool live = m < p.M;                                   // whole 8-lane groups agree: the shuffles stay inside the group
+    float v[NI][8], x[NI][8];
+    float sx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = (l + 8 * i) * 8, half = n / WN, cn = n - half * WN;
+      const float* sp = smem_f + ((wy * 2 + half) * 32 + row) * SLD + cn;
+      Vec<float>::load(sp, v[i]); Vec<float>::load(sp + 4, v[i] + 4);
+      H16<FL>::load8(reinterpret_cast<const bf16*>(&q.xr[ps][i]), x[i]);
+      if (EPI == EPI_LN_TAN && R) {
+        float r8[8];
+        H16<FL>::load8(reinterpret_cast<const bf16*>(&q.rres[ps][i]), r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] += r8[e];
+      }
+      const bf16x8 pk = H16<FL>::pack8(v[i]);                    // the 16-bit value a separate product would have stored
+      if (EPI == EPI_LN_TAN && live) *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = pk;
+      H16<FL>::load8(reinterpret_cast<const bf16*>(&pk), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sx += x[i][e];
+    }
+    const float mean = seg8_sum(sx) * inv_c;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[i][e] -= mean; vs += x[i][e] * x[i][e]; }
+    const float rstd = rsqrtf(seg8_sum(vs) * inv_c + p.ln_eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (EPI == EPI_LN_ADJ) v[i][e] *= gam[i][e];
+        x[i][e] *= rstd;                                         // xhat
+        s1 += v[i][e];
+        s2 += x[i][e] * v[i][e];
+      }
+    const float m1 = seg8_sum(s1) * inv_c, m2 = seg8_sum(s2) * inv_c;
+    if (!live) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = (l + 8 * i) * 8;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float w = rstd * (v[i][e] - m1 - x[i][e] * m2);
+        o[e] = EPI == EPI_LN_TAN ? w * gam[i][e] : w;
+      }
+      if (EPI == EPI_LN_ADJ && p.accumulate) {
+        float old[8];
+        H16<FL>::load8(reinterpret_cast<const bf16*>(&q.rres[ps][i]), old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += old[e];
+      }
+      H16<FL>::store8((EPI == EPI_LN_TAN ? (bf16*)p.C2 : C) + (long)m * p.ldc + n, o);
+    }
+  }
+}
 
 template <int FL, int WN, int SLD, int EPI>
 __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0, int n0,

@@ -538,6 +538,9 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
 
 // fused epilogues (epilogue.h) live in the ring kernels with 128-column tiles and need the whole K range in one block
 int gemm_epi_supported(int dtype, const GemmArgs& a) {
+  if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ)                // row-complete 128 x 320 tile (gemm_ring64.hip, tile code 520)
+    return dtype != DT_F32 && a.Z1 * a.Z2 == 1 && a.gather == GATHER_NONE && a.N == 320 && a.ldc == 320 && a.M >= 128 && a.K % 64 == 0 && a.zeros &&
+           a.ln_x && a.ln_gamma && !a.A2 && !a.bias && !a.rowbias && a.alpha == 1.f && (a.epi == EPI_LN_ADJ || (a.C2 && !a.accumulate)) && (!a.R || a.ldr % 8 == 0);
   if (dtype == DT_F32 || a.Z1 * a.Z2 != 1 || a.gather != GATHER_NONE || a.N % 128 || a.M <= 0) return 0;
   if (a.epi == EPI_GEGLU_ADJ && a.N % 64) return 0;
   const int dt = gemm_uses_dma(dtype, a);
@@ -639,7 +642,9 @@ GemmPlan gemm_plan(int dtype, const GemmArgs& a) {
       pl.kind = -1;
       return pl;
     }
-    if (const int dt = gemm_uses_dma(dtype, a)) {
+    if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ) {
+      pl.kind = PLAN_RING; pl.tile = 520; s = 1;
+    } else if (const int dt = gemm_uses_dma(dtype, a)) {
       pl.kind = PLAN_RING; pl.tile = dt;
       s = a.epi != EPI_PLAIN ? 1 : gemm_pick_splitk_dma(a, dt);
     } else {

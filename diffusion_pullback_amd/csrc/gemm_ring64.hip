@@ -37,10 +37,12 @@ __device__ inline bf16x8 lds_read_frag(unsigned addr) {
 // threaded through it as read-write operands
 template <int N, int NA, int NB>
 __device__ inline void wait_frags(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
-  static_assert((NA == 1 || NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2 || (NA == 2 && NB == 4)), "fragment counts of the supported wave tiles");
+  static_assert((NA == 1 || NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2 || (NA == 2 && (NB == 4 || NB == 5))), "fragment counts of the supported wave tiles");
   if constexpr (NA == 1) {
     static_assert(NB == 1, "64x64 tile: one fragment each");
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(N));
+  } else if constexpr (NA == 2 && NB == 5) {
+    asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]) : "n"(N));
   } else if constexpr (NA == 2 && NB == 4) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
   } else if constexpr (NA == 2 && NB == 2) {
@@ -206,6 +208,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  LnPre<WN> lnq[(EPI == EPI_LN_TAN || EPI == EPI_LN_ADJ) ? TM : 1];      // LayerNorm epilogues: their row operands, in flight under the K loop
+  if constexpr (EPI == EPI_LN_TAN || EPI == EPI_LN_ADJ) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ln_prefetch<FL, WN, EPI>(p, C, R, wave, lane, m0 + i * 32 + (wave >> 1) * (WM - 32), lnq[i]);
+  }
 
   const int wy = wave >> 1, wx = wave & 1, l31 = lane & 31, lhi = lane >> 5;
   // fragment read addresses inside a stage: row*128 + (((kk*2 + lhi) ^ ((row>>1)&7)) << 4) = fa0 ^ (kk << 5)
@@ -285,6 +292,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     __syncthreads();
     if constexpr ((DPB_ABLATE & 8) != 0) {
       if (stage[lane] == 123.456f) reinterpret_cast<float*>(p.C)[0] = stage[lane + 1];
+    } else if constexpr (EPI == EPI_LN_TAN || EPI == EPI_LN_ADJ) {
+      static_assert(WAVES == 4 && TM == 2, "row-complete LayerNorm epilogue: 2 x 2 waves, 64 staged rows per step");
+      // staged rows: wave pair wy holds tile rows wy*WM + i*32 .. +31; epilogue_ln's row index wy*32 + row maps to tile row wy*WM + i*32 + row
+      epilogue_ln<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + i * 32 + (wave >> 1) * (WM - 32), lnq[i]);
     } else {
       epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb);
     }
@@ -335,6 +346,14 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
     else if (a.epi == EPI_GEGLU_ADJ) { if (a.fl) DPB_RING518(1, EPI_GEGLU_ADJ); else DPB_RING518(0, EPI_GEGLU_ADJ); }
     else { if (a.fl) DPB_RING518(1, EPI_PLAIN); else DPB_RING518(0, EPI_PLAIN); }
 #undef DPB_RING518
+  }
+  else if (tile == 520) {                       // row-complete 128 x 320 tile with a fused LayerNorm epilogue (plain rows, N = 320, no split)
+    if (a.gather != GATHER_NONE || a.N != 320 || sk != 1 || (a.epi != EPI_LN_TAN && a.epi != EPI_LN_ADJ)) { set_error("gemm: tile 520 is the N = 320 LayerNorm-epilogue tile"); return -1; }
+    const dim3 g = tiles(128, 320);
+#define DPB_RING520(FLV, EPIV) hipLaunchKernelGGL((gemm_ring64_kernel<128, 320, 2, GATHER_NONE, 4, FLV, EPIV>), g, dim3(256), 0, st, a)
+    if (a.epi == EPI_LN_TAN) { if (a.fl) DPB_RING520(1, EPI_LN_TAN); else DPB_RING520(0, EPI_LN_TAN); }
+    else { if (a.fl) DPB_RING520(1, EPI_LN_ADJ); else DPB_RING520(0, EPI_LN_ADJ); }
+#undef DPB_RING520
   }
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);

@@ -10,7 +10,7 @@ namespace dpb {
 // C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k]  (+bias[n]) (+rowbias[sample(m)][n]) (+R[z][m][n]) (+C if accumulate)
 // A: plain rows (lda) or gathered NHWC pixels (conv).  B is always [N][K], K contiguous.
 enum { GATHER_NONE = 0, GATHER_CONV = 1, GATHER_CONVT = 2, GATHER_UPCONV = 3 };
-enum { EPI_PLAIN = 0, EPI_GEGLU_TAN = 1, EPI_GEGLU_ADJ = 2 };   // fused epilogues of the ring GEMMs (epilogue.h)
+enum { EPI_PLAIN = 0, EPI_GEGLU_TAN = 1, EPI_GEGLU_ADJ = 2, EPI_LN_TAN = 3, EPI_LN_ADJ = 4 };   // fused epilogues of the ring GEMMs (epilogue.h)
 struct GemmArgs {
   const void* A = nullptr; const void* B = nullptr; void* C = nullptr; const void* R = nullptr;
   const float* bias = nullptr;
@@ -39,6 +39,10 @@ struct GemmArgs {
   // blocks of 64 (a | g); tangent row m belongs to primal sample (m / rows_per_sample) / epi_kps
   int epi = EPI_PLAIN, epi_kps = 1;
   const void* hprim = nullptr;
+  // fused LayerNorm epilogues (row-complete 128 x 320 tile, gemm_ring64.hip): EPI_LN_TAN writes h = acc (+R) to C AND its LayerNorm tangent to C2;
+  // EPI_LN_ADJ adds the LayerNorm adjoint of the product (the cotangent of the LayerNorm OUTPUT) to C.  ln_x: primal LayerNorm input [prows][N]
+  // (row m belongs to primal row ((m / rows_per_sample) / epi_kps) * rows_per_sample + m % rows_per_sample), ln_gamma fp32 [N]
+  const void* ln_x = nullptr; const float* ln_gamma = nullptr; float ln_eps = 1e-5f; void* C2 = nullptr;
   int fl = 0;                         // 16-bit flavour of the specialised kernels: 0 bf16, 1 f16 (filled in by launch_gemm)
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };

@@ -205,3 +205,44 @@ def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
                 assert launches[1][0] < launches[0][0] and launches[1][1] < launches[0][1]
         del net
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_layernorm_fused_into_product_epilogue_matches_separate_kernels(dtype):
+    """The 320-wide products next to a LayerNorm run on a row-complete 128 x 320 ring tile whose epilogue applies the LayerNorm tangent (proj_in /
+    to_out products: h and LN'(h) leave one launch) or adjoint (adjoints of the q / k / v, cross-attention q and FF-in products: the cotangent of the
+    LayerNorm output is never stored).  Against the separate GEMM + LayerNorm kernels (dpb_debug_set("ln_fuse", 0)): same values up to the 16-bit
+    rounding of different fp32 summation orders; one to k tangents, two samples, fewer launches."""
+    from diffusion_pullback_amd import PullbackUNet
+    from diffusion_pullback_amd import lib as L
+    from oracle import unet_sd
+    lib = L.load()
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=32, ctx_len=77)     # 32x32 tokens, C = 320 on the first level
+    p = unet_sd.init_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(2, 4, 32, 32, generator=g); ctx = torch.randn(2, 77, 768, generator=g)
+    net = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=2, max_rank=10, upto=("down", 0), verbose=False)
+    e = net.engine
+    tap = ("down", 0)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    try:
+        for B, k in [(1, 1), (1, 5), (2, 5)]:
+            V = torch.randn(B * k, 4 * 32 * 32, generator=g)
+            U = torch.randn(B * k, e.tap_numel(tap), generator=g)
+            out, launches = {}, {}
+            for fuse in (0, 1):
+                L.check(lib.dpb_debug_set(b"ln_fuse", fuse))
+                e.primal(z[:B], 696.2727, ctx[:B], tap)
+                jv = e.jvp(tap, V).clone(); lj = e.stats()[0]
+                vj = e.vjp(tap, U).clone(); lv = e.stats()[0]
+                out[fuse], launches[fuse] = (jv, vj), (lj, lv)
+            for a, b in zip(out[0], out[1]):
+                assert torch.isfinite(b).all()
+                for i in range(B * k):
+                    assert rel(b[i], a[i]) < tol, (B, k, i, rel(b[i], a[i]))
+            # three LayerNorms per transformer block: all three tangents fused; of the adjoints the two behind K <= 1024 products (q/k/v and
+            # cross-attention q), the one behind the FF-in adjoint (K = 8 C) stays a separate kernel
+            assert launches[1][0] == launches[0][0] - 3 and launches[1][1] == launches[0][1] - 2, launches
+    finally:
+        L.check(lib.dpb_debug_set(b"ln_fuse", 1))
