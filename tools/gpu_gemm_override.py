@@ -16,7 +16,7 @@ def run(override, args, tag):
     for rep in range(2):
         path = os.path.join(ROOT, "gpurun_out", f"ovr_{tag}_{rep}.csv")
         env["DPB_PROFILE_CSV"] = path
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "36", "--warmup", "12"] + args,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-unet-forward", "--no-strong-leg", "--repeats", "3", "--steps", "36", "--warmup", "12"] + args,
                            env=env, capture_output=True, text=True)
         line = json.loads(r.stdout.strip().splitlines()[-1])
         agg = collections.OrderedDict()
