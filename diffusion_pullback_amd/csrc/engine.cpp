@@ -227,7 +227,10 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
       return gemm(e, f);
     }
   }
-  return gemm(e, g, mode == 1 && !shared_out);      // tangent: a following GroupNorm / LayerNorm may add the split-K slabs itself
+  // tangent: a following one-launch GroupNorm / LayerNorm may add the split-K slabs itself.  (Primal / forward-only products too were tried in
+  // round 3 -- bias and time-embedding row added by the consumer: 599 -> 573 launches per B = 2 forward but 7.47 -> 7.55 ms: the slabs are 16x
+  // the bytes of the 16-bit tensor and the primal consumers have nothing to hide them under.)
+  return gemm(e, g, mode == 1 && !shared_out);
 }
 
 int conv_adj(dpb_engine* e, const Op& op, int n) {
@@ -959,6 +962,7 @@ static int primal_pass(dpb_engine* e, const float* x, int batch, float t, const 
   }
   if (e->pstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));   // atomic statistics path accumulates
   e->cur_batch = batch;
+  e->cur_tap = upto_buf; e->pend.on = false;
   const int last = e->producer[upto_buf];
   for (int i = 0; i <= last; ++i)
     if (int r = run_op(e, e->ops[i], MODE_PRIMAL, batch)) return r;

@@ -468,26 +468,35 @@ static int gn_fused_groups(int C, int G, int HW, int CH, int es) {
 // partials in the same fixed order into the fp64 statistics (and finalises the primal ones), so the apply blocks need not each walk them.
 constexpr int GN_RED_MAX = 256;
 template <int MODE>
-__global__ __launch_bounds__(256) void gn_reduce_kernel(GNArgs a, int nblk) {
-  __shared__ double lseg[4][2 * 256];
+__global__ __launch_bounds__(1024) void gn_reduce_kernel(GNArgs a, int nblk) {
+  // one block per sample / tangent: SEG = 1024 / 2G block-range segments per statistic, each added in block order with 32 clamped loads in flight
+  // (a plain loop waits out one L2 round trip per partial: 60 us per launch on the 256 x 256 maps), then the segment sums in segment order
+  __shared__ double lseg[1024];
   const int tid = threadIdx.x, j = blockIdx.x, n2 = 2 * a.G;
+  const int SEG = max(1, 1024 / n2);
   const double inv_n = 1.0 / ((double)a.HW * (a.C / a.G));
   const float* pj = a.part + (long)j * nblk * n2;
-  for (int t = tid; t < 4 * n2; t += 256) {
-    const int q = t / n2, i = t - q * n2;
-    const int b0 = (int)((long)nblk * q / 4), b1 = (int)((long)nblk * (q + 1) / 4);
+  if (tid < SEG * n2) {
+    const int q = tid / n2, i = tid - q * n2;
+    const int b0 = (int)((long)nblk * q / SEG), b1 = (int)((long)nblk * (q + 1) / SEG);
     double acc = 0.0;
-    for (int bb = b0; bb < b1; ++bb) acc += (double)pj[(long)bb * n2 + i];
-    lseg[q][i] = acc;
+    for (int bb = b0; bb < b1; bb += 32) {
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = pj[(long)min(bb + u, b1 - 1) * n2 + i];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += bb + u < b1 ? (double)v[u] : 0.0;
+    }
+    lseg[q * n2 + i] = acc;
   }
   __syncthreads();
+  auto total = [&](int i) { double t = 0.0; for (int q = 0; q < SEG; ++q) t += lseg[q * n2 + i]; return t; };
   double* dst = (MODE == MODE_PRIMAL) ? a.pstats : a.tstats;
   if (MODE != MODE_PRIMAL) {
-    for (int i = tid; i < n2; i += 256) dst[(long)j * n2 + i] = ((lseg[0][i] + lseg[1][i]) + lseg[2][i]) + lseg[3][i];
+    for (int i = tid; i < n2; i += 1024) dst[(long)j * n2 + i] = total(i);
   } else {
-    for (int g = tid; g < a.G; g += 256) {
-      const double s1 = ((lseg[0][2 * g] + lseg[1][2 * g]) + lseg[2][2 * g]) + lseg[3][2 * g];
-      const double s2 = ((lseg[0][2 * g + 1] + lseg[1][2 * g + 1]) + lseg[2][2 * g + 1]) + lseg[3][2 * g + 1];
+    for (int g = tid; g < a.G; g += 1024) {
+      const double s1 = total(2 * g), s2 = total(2 * g + 1);
       const double m = s1 * inv_n;
       double v = s2 * inv_n - m * m;
       if (v < 0) v = 0;
@@ -538,7 +547,7 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
   GNArgs b = a;
   b.red = a.det && (int)grid.x <= GN_RED_MAX;     // the apply blocks add the partials themselves (32 ... 256 L2-resident loads per thread quarter)
   hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), lds, st, b, ppb);
-  if (a.det && !b.red) hipLaunchKernelGGL((gn_reduce_kernel<MODE>), dim3(n), dim3(256), 0, st, b, (int)grid.x);
+  if (a.det && !b.red) hipLaunchKernelGGL((gn_reduce_kernel<MODE>), dim3(n), dim3(1024), 0, st, b, (int)grid.x);
   if (MODE == MODE_PRIMAL && !a.det) {
     int ng = a.Bp * a.G;
     hipLaunchKernelGGL(gn_finalize, dim3((ng + 255) / 256), dim3(256), 0, st, a.pstats, ng, 1.0 / ((double)a.HW * (a.C / a.G)), (double)a.eps);

@@ -193,13 +193,16 @@ def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
             try:
                 for lazy in (0, 1):
                     L.check(lib.dpb_debug_set(b"lazy_reduce", lazy))
+                    fw = e.forward(z[:B], 696.2727, ctx[:B], tap).clone()      # forward-only pass (primal products never defer)
                     e.primal(z[:B], 696.2727, ctx[:B], tap)
+                    hp = e.read(tap).clone()
                     jv = e.jvp(tap, V).clone(); lj = e.stats()[0]
                     vj = e.vjp(tap, U).clone(); lv = e.stats()[0]
-                    out[lazy], launches[lazy] = (jv, vj), (lj, lv)
+                    out[lazy], launches[lazy] = (jv, vj, hp, fw), (lj, lv)
             finally:
                 L.check(lib.dpb_debug_set(b"lazy_reduce", 1))
-            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), (dtype, B, k)
+            assert all(torch.equal(a, b) for a, b in zip(out[0], out[1])), (dtype, B, k)
+            assert torch.equal(out[1][2], out[1][3])
             print(dtype, B, k, "launches (jvp, vjp): separate reduce", launches[0], "deferred", launches[1])
             if dtype == torch.bfloat16 and k == 5:
                 assert launches[1][0] < launches[0][0] and launches[1][1] < launches[0][1]
@@ -246,3 +249,30 @@ def test_layernorm_fused_into_product_epilogue_matches_separate_kernels(dtype):
             assert launches[1][0] == launches[0][0] - 3 and launches[1][1] == launches[0][1] - 2, launches
     finally:
         L.check(lib.dpb_debug_set(b"ln_fuse", 1))
+
+
+def test_forward_only_pass_matches_the_stashing_pass_and_invalidates_it():
+    """dpb_forward (the U-Net calls of the DDIM / guidance loop, edit.py:454-458): same output bits as dpb_primal + dpb_read_buffer, GEGLU inputs
+    left untouched, and no stash -- dpb_jvp / dpb_vjp / dpb_pullback_iterate refuse until the next dpb_primal (no silent use of stale state)."""
+    from diffusion_pullback_amd import PullbackUNet
+    from diffusion_pullback_amd import lib as L
+    from oracle import unet_sd
+    f = load_golden("pullback_zt_tiny.pt")
+    cfg = unet_sd.SDConfig(**f["cfg"])
+    p = unet_sd.init_params(cfg, seed=f["seed"], gain=f["gain"])
+    for dtype in (torch.float32, torch.bfloat16):
+        net = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=2, max_rank=3, verbose=False)
+        e = net.engine
+        z = torch.cat([f["z"], f["z"].flip(-1)]); ctx = f["ctx"].expand(2, -1, -1)
+        e.primal(z, float(f["t"]), ctx, "eps")
+        a = e.read("eps").clone()
+        b = e.forward(z, float(f["t"]), ctx, "eps")
+        assert torch.equal(a, b)
+        with pytest.raises(L.DpbError):
+            e.jvp("eps", torch.randn(2, e.n_in))
+        with pytest.raises(L.DpbError):
+            e.vjp("eps", torch.randn(2, e.tap_numel("eps")))
+        e.primal(z, float(f["t"]), ctx, ("mid", 0))                 # a stashing pass makes the engine differentiable again
+        assert torch.isfinite(e.jvp(("mid", 0), torch.randn(2, e.n_in))).all()
+        # forward() twice in a row: the first one must not have clobbered anything the second one reads (GEGLU factors are NOT written)
+        assert torch.equal(e.forward(z, float(f["t"]), ctx, "eps"), b)
