@@ -82,7 +82,7 @@ struct dpb_engine {
   size_t pstats_off = 0, pstats_bytes = 0, tstats_off = 0, tstats_bytes = 0, gnpart = 0, gnpart_bytes = 0, gnticket = 0;
   size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20, zeros = 0;
   size_t orth_stride = 0;                  // re-orthonormalisation scratch per sample of the batch
-  size_t pbV = 0, pbW = 0, pbVn = 0;       // pullback loop fp32 staging
+  size_t pbW = 0;                          // pullback loop fp32 staging of W = J^T J V
   size_t temb_host_stage = 0;
   int cur_batch = 0;
   std::vector<int> uses;            // buffer -> number of ops reading it (in0 / in1 / in2 / res)
@@ -895,7 +895,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   e->slab = take(e->slab_bytes);
   e->zeros = take(256);
   const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
-  e->pbV = 0; e->pbW = take((size_t)e->maxT * nx * sizeof(float)); e->pbVn = take((size_t)e->maxT * nx * sizeof(float));
+  e->pbW = take((size_t)e->maxT * nx * sizeof(float));
   e->ws_bytes = off;
   e->ginit.assign(nb, 0);
   *out = e;
@@ -1058,7 +1058,6 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
   const int nt = k * B;
   const long N = (long)e->bufs[e->x_buf].rows * e->x_channels;
   float* Wm = (float*)(e->ws + e->pbW);
-  float* Vn = (float*)(e->ws + e->pbVn);
   long launches = 0; double fl = 0, gb = 0;
   auto body = [&]() -> int {                        // one power iteration: k JVPs, k VJPs, re-orthonormalisation, V <- V_new; no host sync
     if (int r = dpb_jvp(e, tap, V, nt, U)) return r;
@@ -1066,10 +1065,9 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
     if (int r = dpb_vjp(e, tap, U, nt, Wm)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
     for (int b = 0; b < B; ++b)                     // independent k x N re-orthonormalisation per sample
-      if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, Vn + (long)b * k * N, s + b * k, conv + 2 * b,
+      if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, V + (long)b * k * N, s + b * k, conv + 2 * b,   // in place: see dpb.h
                            e->ws + e->orth + (size_t)b * e->orth_stride, k, N, e->stream)) return r;
-    DPB_CHECK(hipMemcpyAsync(V, Vn, sizeof(float) * nt * N, hipMemcpyDeviceToDevice, e->stream));
-    launches += 4 * B + 1;
+    launches += 4 * B;
     return 0;
   };
   int it = 0;
@@ -1158,13 +1156,14 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* path) {
   DPB_CHECK(hipStreamSynchronize(e->stream));
   FILE* f = fopen(path, "w");
   if (!f) return fail("cannot open %s", path);
-  fprintf(f, "idx,big,gather,M,N,K,Z,us,tflops\n");
+  fprintf(f, "idx,big,gather,M,N,K,Z,us,tflops,raw_us,bracket_overhead_us\n");   // us = raw_us - bracket_overhead_us (calibrated empty-bracket time)
   int i = 0;
   for (auto& p : e->prof) {
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, p.a, p.b);
-    ms = ms > e->prof_overhead_ms ? ms - e->prof_overhead_ms : 0.f;
-    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.2f\n", i++, p.big, p.gather, p.M, p.N, p.K, p.Z, ms * 1e3, ms > 0 ? p.flops / (ms * 1e-3) / 1e12 : 0.0);
+    float raw = 0;
+    (void)hipEventElapsedTime(&raw, p.a, p.b);
+    const float ms = raw > e->prof_overhead_ms ? raw - e->prof_overhead_ms : 0.f;
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.2f,%.2f,%.2f\n", i++, p.big, p.gather, p.M, p.N, p.K, p.Z, ms * 1e3, ms > 0 ? p.flops / (ms * 1e-3) / 1e12 : 0.0,
+            raw * 1e3, e->prof_overhead_ms * 1e3);
   }
   fclose(f);
   return 0;
@@ -1181,6 +1180,12 @@ int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double*
     ms = ms > e->prof_overhead_ms ? ms - e->prof_overhead_ms : 0.f;
     *count += 1; *total_ms += ms; *flops += p.flops;
   }
+  return 0;
+}
+
+int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms) {
+  if (!e || !bracket_overhead_ms) return fail("null argument");
+  *bracket_overhead_ms = e->prof_overhead_ms;
   return 0;
 }
 

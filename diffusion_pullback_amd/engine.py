@@ -195,6 +195,12 @@ class Engine:
         L.check(self.lib.dpb_engine_profile_read(self.h, int(big_tile), C.byref(n), C.byref(ms), C.byref(f)))
         return n.value, ms.value, f.value
 
+    def profile_overhead_ms(self) -> float:
+        """the calibrated empty-bracket time subtracted from every launch of profile_read / profile_dump"""
+        v = C.c_double()
+        L.check(self.lib.dpb_engine_profile_overhead(self.h, C.byref(v)))
+        return v.value
+
     def stats(self):
         n = C.c_int64(); f = C.c_double(); b = C.c_double()
         L.check(self.lib.dpb_engine_stats(self.h, C.byref(n), C.byref(f), C.byref(b)))

@@ -76,6 +76,7 @@ SYMBOLS = {
     "dpb_debug_gemm_plan": (_I, [_I, _I, _I, _I, _I, _I, _I, _L, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "dpb_engine_profile_dump": (_I, [_P, C.c_char_p]),
     "dpb_engine_profile_read": (_I, [_P, _I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dpb_engine_profile_overhead": (_I, [_P, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -119,7 +119,8 @@ int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
 
 /* Thin SVD of W [k][N] (fp32, k <= 56): V rows = right singular vectors (descending), s = sqrt(singular values),
  * conv[0] = ||V - Vprev||_2, conv[1] = max(|V - Vprev| - 1e-5|V|).  scratch: device memory of >= dpb_orth_scratch_bytes(k, N) bytes (Gram
- * matrix and distance partials per block, added in block order: the result is bitwise reproducible).
+ * matrix and distance partials per block, added in block order: the result is bitwise reproducible).  V may alias Vprev (in place:
+ * every element of Vprev is read by the thread that overwrites it, after the Gram pass has finished with it).
  * Replaces: torch.linalg.svd + dist/allclose inputs, utils.py:799-806.  Engine-independent. */
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
              void* hip_stream);
@@ -153,6 +154,9 @@ int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops,
 int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
+/* The per-launch times of _read / _dump are event-bracket times minus a calibrated empty-bracket time (measured when profiling is switched on);
+ * this returns that correction so that the raw bracket times can be reconstructed (raw = reported + overhead per launch). */
+int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms);
 /* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
  * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands;
  * 600: halo-tile 3x3 convolution), "gemm_splitk" (n), "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block
