@@ -245,3 +245,60 @@ def test_gemm_override_environment_changes_the_plan_of_the_named_shape_only():
     assert forced[1] == base[1]                                            # an unnamed shape keeps its plan
     assert base[2] == [2, 518, 1] and forced[2] == [2, 515, 1]             # 2 x 52 MB of slabs do not fit 64 MB: the forced split is clamped to 1
     assert forced[3][2] == 1                                               # and with 1 MB of scratch nothing splits
+
+
+def test_bench_names_the_baseline_config_it_measures():
+    """bench.py's config.workload: every --op down/up run is BASELINE configs[4] with its tap, k = 10 / edit ctx / strong mode is configs[3],
+    DDPM is configs[1], the default is configs[2] (r02 review: 16 sweep lines were labelled configs[2])."""
+    import argparse
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    A = lambda **kw: argparse.Namespace(**{**dict(workload="sd15", k=5, ctx="null"), **kw})
+    assert bench.workload_name(A(), False, ("mid", 0)).startswith("BASELINE configs[2]")
+    assert "configs[4]" in bench.workload_name(A(), False, ("up", 3)) and "up_block_3" in bench.workload_name(A(), False, ("up", 3))
+    assert "configs[4]" in bench.workload_name(A(), False, ("down", 0)) and "down_block_0" in bench.workload_name(A(), False, ("down", 0))
+    assert bench.workload_name(A(k=10, ctx="edit"), False, ("mid", 0)).startswith("BASELINE configs[3]")
+    assert bench.workload_name(A(), True, ("mid", 0)).startswith("BASELINE configs[3]")
+    assert bench.workload_name(A(workload="ddpm256"), False, ("mid", 0)).startswith("BASELINE configs[1]")
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_running_build(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC file ONLY if that file records the source hash of the library that is running; otherwise null."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from diffusion_pullback_amd import lib as L
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    kern = {"kernels": {"k<1>": {"launches": 3, "fetch_kb_per_launch": 10.0, "write_kb_per_launch": 4.0}}}
+    (prof / "r99_pmc_traffic_sd15_mid_k5_bf16.json").write_text(json.dumps({**kern, "_src_hash": "not-this-build"}))
+    monkeypatch.setattr(L, "_built_hash", lambda: "abc123")
+    t, note = bench.pmc_traffic("k<1>", True)
+    assert t is None and "null" in note
+    (prof / "r98_pmc_traffic_sd15_mid_k5_bf16.json").write_text(json.dumps({**kern, "_src_hash": "abc123"}))
+    t, note = bench.pmc_traffic("k<1>", True)
+    assert t == (2 * 10.0 + 4.0) * 1024 and "r98" in note
+    assert bench.pmc_traffic("k<1>", False)[0] is None
+
+
+def test_spectrum_for_tap_shapes_the_last_self_attention_of_the_prefix():
+    from diffusion_pullback_amd import configs as cf
+    assert cf.Spectrum.for_tap("mid", 0).also == ()
+    assert cf.Spectrum.for_tap("down", 1).also == ("down_blocks.1.attentions.1",)
+    assert cf.Spectrum.for_tap("down", 3).also == ("down_blocks.2.attentions.1",)          # down3 has no attention of its own
+    up = cf.Spectrum.for_tap("up", 3)
+    assert up.also == ("up_blocks.3.attentions.2",) and up.amp == 100.0                   # two shaped layers in series: fp16 range
+    cfg = cf.SDConfig(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(2, 2),
+                      cross_dim=64, sample_size=16, ctx_len=77)
+    a = cf.sd_init_params(cfg, seed=0, spectrum=cf.Spectrum())
+    b = cf.sd_init_params(cfg, seed=0, spectrum=cf.Spectrum(also=("down_blocks.0.attentions.0",)))
+    changed = sorted(k for k in a if not torch.equal(a[k], b[k]))
+    assert changed == ["down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight"]
