@@ -770,8 +770,9 @@ template <int D, int TJ> struct SHK {
   static constexpr int NS = (D + 15) / 16, DP = NS * 16, ND = (D + 31) / 32, DO = ND * 32;
   static constexpr int LDR = (DP > DO ? DP : DO) + DPB_ATT_PAD, ROW_ELEMS = BI * LDR;
   static constexpr int NTILE = 1 + TJ, CPR = DP / 8;                // tile 0 Q, 1 + t gO_t
-  static constexpr int NLD = NTILE / 2;
-  static_assert(NTILE % 2 == 0 && 2 * BI * CPR == NT, "one load per thread covers exactly one pair of tiles");
+  static constexpr int CPT = BI * CPR;                              // 16-byte chunks per tile
+  static constexpr int NLD = NTILE * CPT / NT;                      // loads per thread and stage (chunk c = tid + NT i)
+  static_assert(NTILE * CPT % NT == 0, "whole loads per thread");
 };
 
 template <int D, int TJ, int FL>
@@ -787,19 +788,19 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
   const long LC = (long)a.L * a.C, LCo = (long)a.L * a.Co;
   const bf16* Qp = a.Q + b * LC + h * D;
   const float* stp_ = a.stats + ((long)b * a.H + h) * a.L * 2;
-  // ---- tile loader: load i moves tiles (2i, 2i + 1); tile 0 = Q (row stride C), tile 1 + t = gO_t (row stride Co)
-  const int lt = tid >= S::BI * S::CPR ? 1 : 0;
-  const int lrow = (tid % (S::BI * S::CPR)) / S::CPR, lcc = (tid % S::CPR) * 8;
+  // ---- tile loader: chunk c = tid + NT i  ->  (tile, row, 16-byte column), fixed per thread; tile 0 = Q (row stride C), tile 1 + t = gO_t (row stride Co)
   const bf16* lsrc[S::NLD];
   long lstr[S::NLD];
+  int ldst[S::NLD];
 #pragma unroll
   for (int i = 0; i < S::NLD; ++i) {
-    const int tile = 2 * i + lt;
+    const int c = tid + i * S::NT, tile = c / S::CPT, lrow = (c % S::CPT) / S::CPR, lcc = (c % S::CPR) * 8;
     const bf16* base = nullptr;
     lstr[i] = tile == 0 ? a.C : a.Co;
     if (tile == 0) base = Qp;
     else if (tile - 1 < nj) base = a.gO + (long)(j0 + tile - 1) * LCo + h * D;
     lsrc[i] = (base && lcc < D) ? base + (long)lrow * lstr[i] + lcc : nullptr;
+    ldst[i] = tile * S::ROW_ELEMS + lrow * S::LDR + lcc;
   }
   uint4 rg[S::NLD];
   float dreg = 0.f;
@@ -811,8 +812,7 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
   };
   auto commit = [&](int par) {
 #pragma unroll
-    for (int i = 0; i < S::NLD; ++i)
-      *reinterpret_cast<uint4*>(sm + (par * S::NTILE + 2 * i + lt) * S::ROW_ELEMS + lrow * S::LDR + lcc) = rg[i];
+    for (int i = 0; i < S::NLD; ++i) *reinterpret_cast<uint4*>(sm + par * S::NTILE * S::ROW_ELEMS + ldst[i]) = rg[i];
     if (dt_ < TJ) sD[par][dt_][dq_] = dreg;
   };
   // ---- roles (own copy of the stage loop each, same barrier sequence)
@@ -1219,25 +1219,36 @@ int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
   static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernel (tuning switch)
   if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
-  if (f.d == 40 && (multi & 1) && f.L % 128 == 0 && nt % f.kps == 0) {
+  // The shared-probability adjoint kernels serve head dim 40 (the SD-1.x 64x64 level).  They are instantiated for d = 64 too (SD-2.x: every level), but
+  // there they measured no gain -- SD-2.1-base mid, k = 5, fp16: 8.41 ms per iteration on the per-cotangent kernels, 8.43 with the query-major one,
+  // 8.54 with both (5 heads at L = 4096 give the key-major kernel 320 blocks = 1.25 rounds of one block per CU) -- so d = 64 takes them only when
+  // bit 2 of the attn_shared switch asks (the parity test does).
+  const int shared = g_attn_shared;
+  const bool dsh = f.d == 40 || (f.d == 64 && (shared & 4));
+  if (dsh && (multi & 1) && f.L % 128 == 0 && nt % f.kps == 0) {
     constexpr int TJ = 5;
     const int ngrp = (f.kps + TJ - 1) / TJ;
     const dim3 gq(f.L / 128, (nt / f.kps) * f.H * ngrp);
-    if (f.fl) hipLaunchKernelGGL((attn_adj_q_multi_kernel<40, TJ, 1>), gq, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_adj_q_multi_kernel<40, TJ, 0>), gq, dim3(256), 0, st, a);
+#define DPB_ADJQ(DV, FLV) hipLaunchKernelGGL((attn_adj_q_multi_kernel<DV, TJ, FLV>), gq, dim3(256), 0, st, a)
+    if (f.d == 40) { if (f.fl) DPB_ADJQ(40, 1); else DPB_ADJQ(40, 0); }
+    else { if (f.fl) DPB_ADJQ(64, 1); else DPB_ADJQ(64, 0); }
+#undef DPB_ADJQ
   } else {
     DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_q_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   }
-  const int shared = g_attn_shared;
-  if (f.d == 40 && (shared & 2) && f.L % 64 == 0 && f.kps >= 4 && nt % f.kps == 0 && f.Drow) {
+  if (dsh && (shared & 2) && f.L % 64 == 0 && f.kps >= 4 && nt % f.kps == 0 && f.Drow) {
     constexpr int TJ = 5;
     const int ngrp = (f.kps + TJ - 1) / TJ;
     const dim3 gs(f.L / 64, (nt / f.kps) * f.H * ngrp);
     const unsigned nrd = (unsigned)(((long)nt * f.L * f.H + 255) / 256);
-    if (f.fl) hipLaunchKernelGGL((attn_rowdot_kernel<40, 1>), dim3(nrd), dim3(256), 0, st, a, nt);
-    else hipLaunchKernelGGL((attn_rowdot_kernel<40, 0>), dim3(nrd), dim3(256), 0, st, a, nt);
-    if (f.fl) hipLaunchKernelGGL((attn_adj_kv_shared_kernel<40, TJ, 1>), gs, dim3(SHK<40, TJ>::NT), 0, st, a);
-    else hipLaunchKernelGGL((attn_adj_kv_shared_kernel<40, TJ, 0>), gs, dim3(SHK<40, TJ>::NT), 0, st, a);
+#define DPB_ADJKV(DV, FLV)                                                                                   \
+    do {                                                                                                       \
+      hipLaunchKernelGGL((attn_rowdot_kernel<DV, FLV>), dim3(nrd), dim3(256), 0, st, a, nt);                  \
+      hipLaunchKernelGGL((attn_adj_kv_shared_kernel<DV, TJ, FLV>), gs, dim3(SHK<DV, TJ>::NT), 0, st, a);      \
+    } while (0)
+    if (f.d == 40) { if (f.fl) DPB_ADJKV(40, 1); else DPB_ADJKV(40, 0); }
+    else { if (f.fl) DPB_ADJKV(64, 1); else DPB_ADJKV(64, 0); }
+#undef DPB_ADJKV
   } else if (att_block_waves(f.d, f.L, nt * f.H) == 4 && f.d == 40) {
     dim3 g4(f.L / 128, nt * f.H);
     if (f.fl) hipLaunchKernelGGL((attn_adj_kv_kernel<40, 1, 4>), g4, dim3(256), 0, st, a);

@@ -163,7 +163,8 @@ int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms
  * order per XCD), "gn_deterministic" (1, default: GroupNorm statistics of the two-pass kernels reduced in a fixed order -> bitwise
  * reproducible runs; 0 = the round-1 atomic statistics, A/B only), "graph_iterate" (0|1: dpb_pullback_iterate replays a captured hipGraph on a non-default stream;
  * measured equal to eager launches, default 0), "attn_shared" (2, default: shared-probability key-major adjoint of the head-dim-40
- * self-attention layers; 0 = the per-cotangent kernel of round 2), "lazy_reduce" (1, default: a split-K product consumed by a one-launch GroupNorm or a
+ * self-attention layers; 0 = the per-cotangent kernel of round 2; 6 = also route head dim 64 (SD-2.x) through the shared-probability adjoint kernels, measured
+ * no faster there), "lazy_reduce" (1, default: a split-K product consumed by a one-launch GroupNorm or a
  * LayerNorm leaves its fp32 slabs to that kernel instead of running splitk_reduce_kernel; 0 = always reduce; bitwise the same results).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
  * kernel and split count per product shape; DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,

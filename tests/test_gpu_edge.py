@@ -134,17 +134,20 @@ def test_graph_replay_of_the_power_iteration_matches_eager_launches():
         L.check(lib.dpb_debug_set(b"graph_iterate", 0))
 
 
+@pytest.mark.parametrize("heads", [8, 5], ids=["d40", "d64"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype):
+def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype, heads):
     """attn_adj_kv_shared_kernel (head dim 40: one block carries all cotangents of a sample, P computed once by producer waves) against the
     per-cotangent kernel of round 2 (dpb_debug_set("attn_shared", 0)) on the same inputs: full and ragged cotangent groups (k = 5, 4, 7 = 5 + 2,
-    10), two samples, accumulate flags as the tape sets them.  The two round P / gS to 16 bit at slightly different places."""
+    10), two samples, accumulate flags as the tape sets them.  The two round P / gS to 16 bit at slightly different places.  Head dim 40 (SD-1.x, the
+    default route) and 64 (SD-2.x: 5 heads at C = 320; measured no faster there, so opt-in through bit 2 of the switch, which also moves the query-major
+    pass to its multi-cotangent kernel -- both instantiations are held to the per-cotangent kernels here)."""
     from diffusion_pullback_amd import PullbackUNet
     from diffusion_pullback_amd import lib as L
     from oracle import unet_sd
     lib = L.load()
     cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
-                           heads=(8, 8), cross_dim=768, sample_size=32, ctx_len=77)     # 32x32 tokens = 1024, 8 heads of 40
+                           heads=(heads, heads), cross_dim=768, sample_size=32, ctx_len=77)     # 32x32 tokens = 1024; 8 heads of 40 or 5 of 64
     p = unet_sd.init_params(cfg, seed=3)
     g = torch.Generator().manual_seed(4)
     z = torch.randn(2, 4, 32, 32, generator=g); ctx = torch.randn(2, 77, 768, generator=g)
@@ -157,11 +160,12 @@ def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype):
             V = torch.randn(B * k, 4 * 32 * 32, generator=g)
             U = torch.randn(B * k, e.tap_numel(tap), generator=g)
             out = {}
-            for bits in (0, 2):
+            on = 2 if heads == 8 else 6
+            for bits in (0, on):
                 L.check(lib.dpb_debug_set(b"attn_shared", bits))
                 e.primal(z[:B], 696.2727, ctx[:B], tap)
                 out[bits] = (e.jvp(tap, V).clone(), e.vjp(tap, U).clone())
-            for a, b in zip(out[0], out[2]):
+            for a, b in zip(out[0], out[on]):
                 assert torch.isfinite(b).all()
                 assert rel(b, a) < tol, (B, k, rel(b, a))
                 for i in range(B * k):                                  # every tangent / cotangent, not just the norm of the stack
