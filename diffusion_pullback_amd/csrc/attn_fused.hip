@@ -49,7 +49,9 @@ template <int D, int W = att_waves(D)> struct FA {
 // commit() writes them to LDS after the barrier, so HBM/L2 latency overlaps the compute.
 // Row tile: [BI rows][D cols] sub-matrix (row stride gs) -> LDS [BI][LDR], columns D..DP zero filled.
 template <int D, int NTH = FA<D>::NT> struct RowRegs { uint4 v[(FA<D>::BI * (FA<D>::DP / 8) + NTH - 1) / NTH]; };
-template <int D, int NTH = FA<D>::NT>
+// ONE != 0: column D of the tile (the first padding column, when the score padding DP > D provides one) holds the 16-bit constant ONE (1.0) instead
+// of 0 -- as an A-operand row of the output products it makes the MFMA return the plain row sum of the B operand (attn_jvp_kernel's delta)
+template <int D, int NTH = FA<D>::NT, unsigned ONE = 0>
 __device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<D, NTH>& rg, int tid) {
   using F = FA<D>;
   constexpr int CPR = F::DP / 8, N = (F::BI * CPR + NTH - 1) / NTH;
@@ -57,7 +59,7 @@ __device__ inline void fetch_row(const bf16* __restrict__ src, long gs, RowRegs<
   for (int i = 0; i < N; ++i) {
     const int c = tid + i * NTH;
     const int r = c / CPR, cc = (c % CPR) * 8;
-    rg.v[i] = make_uint4(0, 0, 0, 0);
+    rg.v[i] = make_uint4(ONE != 0 && cc == D ? ONE : 0u, 0, 0, 0);
     if (c < F::BI * CPR && cc < D) rg.v[i] = *reinterpret_cast<const uint4*>(src + (long)r * gs + cc);
   }
 }
@@ -281,7 +283,17 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
   load_outer_frags<D>(dQp + (long)q * a.C, dqf, lhi);
   const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
   const float c2 = a.scale * 1.44269504088896f;
-  const float m2 = st[0] * 1.44269504088896f, il = st[1];
+  const float m2 = st[0] * 1.44269504088896f - __builtin_log2f(st[1]);   // 1 / l folded into the exponent: p = exp2(c2 s - m2), no multiply per probability
+  // delta_i = sum_j x_ij as a row of the output MFMAs: column D of the V tile (a padding column of the 32-wide output tiles) holds 1.0, so element
+  // D of the accumulator row IS the sum of the (16-bit) x operand -- 16 dependent v_add per 32 keys less in a loop whose VALU time equals its MFMA time
+  constexpr bool SUMROW = F::DO > D && ((D % 32) & 4) == 0;
+  constexpr unsigned ONE16 = FL ? 0x3C00u : 0x3F80u, VONE = (SUMROW && F::DP > D) ? ONE16 : 0u;
+  if constexpr (SUMROW && F::DP == D) {                 // no padding chunk in the committed rows: the column is written once
+    for (int r = tid; r < F::BI; r += F::NT) {
+      reinterpret_cast<unsigned short*>(sV)[r * F::LDR + D] = (unsigned short)ONE16;
+      reinterpret_cast<unsigned short*>(sdV)[r * F::LDR + D] = 0;
+    }
+  }
   f32x16 acc[F::ND];
 #pragma unroll
   for (int d = 0; d < F::ND; ++d)
@@ -290,7 +302,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
   float delta = 0.f;
   RowRegs<D, F::NT> rK, rdK, rV, rdV;
   fetch_row<D, F::NT>(Kp, a.C, rK, tid); fetch_row<D, F::NT>(dKp, a.C, rdK, tid);
-  fetch_row<D, F::NT>(Vp, a.C, rV, tid); fetch_row<D, F::NT>(dVp, a.C, rdV, tid);
+  fetch_row<D, F::NT, VONE>(Vp, a.C, rV, tid); fetch_row<D, F::NT>(dVp, a.C, rdV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();                      // previous stage fully consumed
     commit_row<D, F::NT>(rK, sK, tid); commit_row<D, F::NT>(rdK, sdK, tid); commit_row<D, F::NT>(rV, sV, tid); commit_row<D, F::NT>(rdV, sdV, tid);
@@ -298,7 +310,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
     if (k0 + F::BI < a.L) {               // prefetch the next stage under this stage's MFMAs
       const int k1 = k0 + F::BI;
       fetch_row<D, F::NT>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, F::NT>(dKp + (long)k1 * a.C, a.C, rdK, tid);
-      fetch_row<D, F::NT>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_row<D, F::NT>(dVp + (long)k1 * a.C, a.C, rdV, tid);
+      fetch_row<D, F::NT, VONE>(Vp + (long)k1 * a.C, a.C, rV, tid); fetch_row<D, F::NT>(dVp + (long)k1 * a.C, a.C, rdV, tid);
     }
     // Fragment reads run one step ahead of their MFMAs (explicit software pipeline; the compiler otherwise sinks every
     // ds_read to just before its use and each MFMA group waits out the LDS latency): the second-stage V^T / dV^T
@@ -345,9 +357,9 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
       float p[16], x[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il;
+        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2);
         x[r] = p[r] * (a.scale * ds[r]);
-        delta += x[r];
+        if constexpr (!SUMROW) delta += x[r];
       }
       bf16x8 pb[2], xb[2];
       pack_b<FL>(p, pb);
@@ -365,7 +377,8 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
         }
     }
   }
-  delta += __shfl_xor(delta, 32, 64);
+  if constexpr (SUMROW) delta = __shfl(acc[D / 32][((D % 32) & 3) + 4 * ((D % 32) >> 3)], l31, 64);   // output column D lives in the lhi = 0 lanes
+  else delta += __shfl_xor(delta, 32, 64);
   // dO[q][dcol] = acc - delta * O[q][dcol];  lane owns query q, register r <-> dcol = d*32 + (r&3) + 8*(r>>2) + 4*lhi
   const long LCo = (long)a.L * a.Co;
   const bf16* Op = a.O + b * LCo + (long)q * a.Co + h * D;
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   Dq += __shfl_xor(Dq, 32, 64);
   const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
   const float c2 = a.scale * 1.44269504088896f;
-  const float m2 = st[0] * 1.44269504088896f, il = st[1];
+  const float m2 = st[0] * 1.44269504088896f - __builtin_log2f(st[1]);   // 1 / l folded into the exponent
   f32x16 acc[F::ND];
 #pragma unroll
   for (int d = 0; d < F::ND; ++d)
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
       }
       float gs[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gs[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il * (gp[r] - Dq);
+      for (int r = 0; r < 16; ++r) gs[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * (gp[r] - Dq);
       bf16x8 gsb[2];
       pack_b<FL>(gs, gsb);
 #pragma unroll
@@ -502,6 +515,8 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
   const long LC = (long)a.L * a.C, LCo = (long)a.L * a.Co;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
+  // (Folding D_t into the gP product -- 1.0 in the padding columns D, D + 1 of the V tile, -D_t split into two 16-bit halves in the cotangent fragments,
+  // so that the MFMA returns gP_t - D_t -- removes 16 subtracts per cotangent and 32 keys and measured neutral: 8.742 / 8.736 vs 8.737 ms per iteration.)
   bf16x8 qf[F::NS], gof[TJ][F::NS];
   load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
   float Dq[TJ];
@@ -529,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
   }
   const float* st = a.stats + (((long)b * a.H + h) * a.L + q) * 2;
   const float c2 = a.scale * 1.44269504088896f;
-  const float m2 = st[0] * 1.44269504088896f, il = st[1];
+  const float m2 = st[0] * 1.44269504088896f - __builtin_log2f(st[1]);   // 1 / l folded into the exponent
   f32x16 acc[TJ][F::ND];
 #pragma unroll
   for (int t = 0; t < TJ; ++t)
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
         for (int d = 0; d < F::ND; ++d) ktf[ks][d] = lds_tr_frag(sK, F::LDR, kb * 32 + ks * 16, d * 32, lane);   // K^T from the K row tile
       float p[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2) * il;
+      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2);
 #pragma unroll
       for (int t = 0; t < TJ; ++t) {
         if (t < nj) {
@@ -616,7 +631,7 @@ template <int D, int FL, int W = att_waves(D)>
 __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv_kernel(FusedArgs a) {
   using F = FA<D, W>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
-  __shared__ float sstat[3][F::BI];          // m*log2e, 1/l, D per query of the stage
+  __shared__ float sstat[2][F::BI];          // m*log2e - log2(1/l), D per query of the stage
   bf16* sQ = sm; bf16* sgO = sQ + F::ROW_ELEMS;     // Q^T / gO^T fragments come from these row tiles by LDS transpose reads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
@@ -638,12 +653,11 @@ __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv
 #pragma unroll
     for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
   RowRegs<D, F::NT> rQ, rgO;
-  float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+  float st0 = 0.f, st2 = 0.f;
   auto fetch_stats = [&](int q0) {       // per-query statistics of a stage, D_q = gO_q . O_q
     if (tid < F::BI) {
       const int qq = q0 + tid;
-      st0 = stp_[2 * qq] * 1.44269504088896f;
-      st1 = stp_[2 * qq + 1];
+      st0 = stp_[2 * qq] * 1.44269504088896f - __builtin_log2f(stp_[2 * qq + 1]);   // 1 / l folded into the exponent
       float dq = 0.f;
       for (int c = 0; c < D; c += 8) {
         float g8[8], o8[8];
@@ -660,7 +674,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv
   for (int q0 = 0; q0 < a.L; q0 += F::BI) {
     __syncthreads();
     commit_row<D, F::NT>(rQ, sQ, tid); commit_row<D, F::NT>(rgO, sgO, tid);
-    if (tid < F::BI) { sstat[0][tid] = st0; sstat[1][tid] = st1; sstat[2][tid] = st2; }
+    if (tid < F::BI) { sstat[0][tid] = st0; sstat[1][tid] = st2; }
     __syncthreads();
     if (q0 + F::BI < a.L) {
       const int q1 = q0 + F::BI;
@@ -681,8 +695,8 @@ __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - sstat[0][qi]) * sstat[1][qi];
-        gs[r] = p[r] * (gp[r] - sstat[2][qi]);
+        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - sstat[0][qi]);
+        gs[r] = p[r] * (gp[r] - sstat[1][qi]);
       }
       bf16x8 pb[2], gsb[2];
       pack_b<FL>(p, pb);
@@ -764,6 +778,8 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(FusedArgs a, int nt) {
 // 4-wave block per CU like attn_adj_q_multi_kernel (3 + 14 TJ MFMAs per 32 keys, dK_t fragments read one tangent ahead): 256 + 256 registers with
 // 10 spilled, ~530 us -- with one wave per SIMD nothing hides the 7 per-tangent fragment reads per 14 MFMAs.  LDS row paddings of 16 / 24 elements
 // instead of 8: no gain either (9.02 / 9.28 vs 8.99 ms per iteration).)
+// (D_t carried by the gP product -- -D_t as two 16-bit halves in the padding columns of the gO_t tiles, 1.0 in the V fragments -- instead of the sD table
+// and a subtract per probability: 2-12 spilled VGPRs at the 168-register budget of 12 waves, 8.858 vs 8.737 ms per iteration; removed.)
 template <int D, int TJ> struct SHK {
   static constexpr int QG = 2, NP = QG, NW = NP + QG * TJ, NT = NW * 64;
   static constexpr int BI = 64;                                     // queries per LDS stage (two 32-query blocks); the stage ring is double-buffered
