@@ -508,16 +508,12 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (force == 67) return 66;
   if (force >= 512 && force <= 517) return force;
   if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
-  if (force == 530) return gemm_astat_supported(a) ? 530 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
   // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
   // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
-  // A-stationary short-K kernel (gemm_ring64.hip): K <= 320 with at least ~half the CUs' worth of 128-row panels
-  static const int astat_env = getenv("DPB_ASTAT") ? atoi(getenv("DPB_ASTAT")) : 0;            // tuning switch: largest N it takes (0 = off)
-  if (astat_env && force == 0 && a.Z1 * a.Z2 == 1 && a.M >= 128 * 128 && a.N <= astat_env && gemm_astat_supported(a)) return 530;
   // 256x256 8-wave tile (half the L2->LDS bytes per flop): plain-row products that give >= 160 such tiles with < 7 % padding and K >= 640
   // -- 12-26 % ahead of the 128x128 ring there, behind it below (profiles/r02_gemm_big_microbench.txt, r02_gemm_split_microbench.txt)
   static const int big_env = getenv("DPB_TILE256") ? atoi(getenv("DPB_TILE256")) : 1;   // tuning switch
@@ -568,7 +564,7 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
     // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
     // profiles/r02_gemm_split_microbench.txt (5120x640: K 1920 / 2560 24 / 32 us unsplit vs 34 / 41 us three-fold, K 5120 52 us two-fold vs
     // 58 unsplit; 1280x3840x1280 25 vs 36 us; 320x10240x1280 18 vs 25 us)
-    if (tile == 518 || tile == 530) return 1;  // one 8-wave block per CU and >= 160 tiles by construction: never split (530: whole-K by construction)
+    if (tile == 518) return 1;                 // one 8-wave block per CU and >= 160 tiles by construction: never split
     if (tiles >= 192) s = (tiles < 256 && nk >= 128) ? 2 : 1;
     else {
       s = std::max<long>(1, (target + tiles / 2) / tiles);
@@ -700,7 +696,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   if (pl.kind == PLAN_HALO) {
     if (int r = launch_conv_halo(a, st)) return r;
   } else if (pl.kind == PLAN_RING) {
-    if (int r = pl.tile == 530 ? launch_gemm_astat(a, st) : pl.tile >= 512 ? launch_gemm_ring64(a, pl.tile, st) : launch_gemm_dma(a, pl.tile, st)) return r;
+    if (int r = pl.tile >= 512 ? launch_gemm_ring64(a, pl.tile, st) : launch_gemm_dma(a, pl.tile, st)) return r;
   } else if (pl.kind == PLAN_REG128) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);
     launch_reg_t<T, 128, 128, 4>(a, grid, st);

@@ -303,177 +303,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   });
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------------
-// A-stationary product for short K (K = 64 NKA <= 320, plain rows, N a multiple of 320): the 64x64-level projections, whose 128x128 tiles spend
-// their time in prologue / epilogue latency (5 K steps of MFMA work per tile: profiles/r01_gemm_ablation.txt).  One 8-wave block owns 128 rows
-// for ALL N.  Its A tile [128][K] is fetched in one burst (every byte in flight at once), moved to REGISTERS (wave (wy, wx) keeps rows 32 wy..+31:
-// 4 NKA fragments), and the weight rows stream past it through a 7-slot ring of [128 columns][64 K] stages that recycles the A region: no per-tile
-// prologue, the ring never drains between column chunks, one barrier per 8 MFMAs and wave.  Columns are processed in super-chunks of 320 (five
-// 32-column accumulators per wave): stage (c, kt) of a super-chunk holds columns 128 c + [0, 128) (c = 2: 64 columns + a zero-page half), K step
-// kt; wave wx takes the fragments at 64 j + 32 wx (j = 0, 1), so both waves of a row group stay busy on the half chunk.  K order per output element
-// is kt = 0 .. NKA-1, kk = 0 .. 3 as in gemm_ring64_kernel: the same bits as the 128x128 tile.
-__device__ __forceinline__ void astat_wait_vm(int stages) {       // 2 DMA instructions per stage and wave
-  if (stages >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if (stages == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (stages == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (stages == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (stages == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-template <int N>
-__device__ __forceinline__ void astat_wait_b(bf16x8& b0, bf16x8& b1) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N)); }
-
-template <int NKA, int FL>
-__global__ __launch_bounds__(512) void gemm_astat_kernel(GemmArgs p) {
-  constexpr int WAVES = 8, NSLOT = 7, SLOT = 128 * 128, SCW = 320, NF = 5, SLD = 36, KK = 4, NST = 3 * NKA;
-  static_assert(NKA >= 1 && NKA <= 5, "the A tile must fit the ring region it is recycled into");
-  __shared__ __attribute__((aligned(128))) char smem[NSLOT * SLOT + WAVES * 32 * SLD * 4];
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1, l31 = lane & 31, lhi = lane >> 5;
-  const int m0 = blockIdx.x * 128, zb = blockIdx.y;
-  const int z1 = zb / p.Z2, z2 = zb % p.Z2;
-  const bf16* A = (const bf16*)p.A + (long)(z1 / p.divA) * p.sA1 + (long)z2 * p.sA2;
-  const bf16* B = (const bf16*)p.B + (long)(z1 / p.divB) * p.sB1 + (long)z2 * p.sB2;
-  bf16* C = (bf16*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2;
-  const bf16* R = p.R ? (const bf16*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 : nullptr;
-  const bf16* zero = (const bf16*)p.zeros;
-  const int nsc = p.N / SCW, T = nsc * NST;
-
-  // ---- DMA geometry, the same for A and B stages: wave instruction i covers rows 8 (2 wave + i) .. +7, lane -> (row, swizzled 16-byte chunk)
-  int drow[2], dkc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pos = (wave * 2 + i) * 64 + lane;
-    drow[i] = pos >> 3;
-    dkc[i] = ((pos & 7) ^ ((drow[i] >> 1) & 7)) * 8;
-  }
-#pragma unroll
-  for (int kt = 0; kt < NKA; ++kt)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + drow[i];
-      const bf16* src = m < p.M ? A + (long)m * p.lda + kt * 64 + dkc[i] : zero;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + kt * SLOT + (wave * 2 + i) * 1024), 16, 0, 0);
-    }
-  // ---- weight stages: stage s = (super-chunk, c, kt) lives in slot (s + 5) % 7 (the A tile holds slots 0 .. NKA-1 until it is in registers)
-  const bf16* bsrc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) bsrc[i] = B + (long)drow[i] * p.ldb + dkc[i];
-  const long cstep = 128L * p.ldb;
-  int issued = 0, islot = 5, ikt = 0, ic = 0;
-  auto issue_b = [&]() {
-    char* st = smem + islot * SLOT;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bf16* src = (ic == 2 && drow[i] >= 64) ? zero : bsrc[i] + ikt * 64;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * 2 + i) * 1024), 16, 0, 0);
-    }
-    ++issued;
-    islot = islot == NSLOT - 1 ? 0 : islot + 1;
-    if (++ikt == NKA) {
-      ikt = 0;
-      const long adv = ic == 2 ? cstep / 2 : cstep;            // columns 0, 128, 256 of a super-chunk, then + 64 to the next one
-      bsrc[0] += adv; bsrc[1] += adv;
-      ic = ic == 2 ? 0 : ic + 1;
-    }
-  };
-  issue_b();
-  issue_b();                                                   // T >= 3
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // the A tile has landed (this wave's part) ...
-  __builtin_amdgcn_s_barrier();                               // ... and everyone's
-  bf16x8 afr[NKA][KK];
-  {
-    const int row = wy * 32 + l31;
-    const unsigned fa0 = row * 128 + ((lhi ^ ((row >> 1) & 7)) << 4);
-#pragma unroll
-    for (int kt = 0; kt < NKA; ++kt)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) afr[kt][kk] = lds_read_frag(lds0 + kt * SLOT + (fa0 ^ (kk << 5)));
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                               // the A region is free: it joins the ring
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (issued < T) issue_b();                                // stages 2 .. 5
-
-  unsigned fb0[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = j * 64 + wx * 32 + l31;
-    fb0[j] = row * 128 + ((lhi ^ ((row >> 1) & 7)) << 4);
-  }
-  f32x16 acc[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-  float* stg = reinterpret_cast<float*>(smem + NSLOT * SLOT) + wave * 32 * SLD;
-
-  int s = 0, slot = 5;
-  // a stage becomes readable: its DMA landed for this wave, then for all (barrier) -- which also says that every wave is done with stage s - 1,
-  // whose slot takes stage s + 6
-  auto stage_begin = [&]() {
-    astat_wait_vm(min(5, T - 1 - s));
-    __builtin_amdgcn_s_barrier();
-    if (issued < T) issue_b();
-  };
-  bf16x8 fb[2][2];
-  for (int sc = 0; sc < nsc; ++sc) {
-    stage_begin();
-    {
-      const unsigned sb = lds0 + slot * SLOT;
-      fb[0][0] = lds_read_frag(sb + fb0[0]);
-      fb[0][1] = lds_read_frag(sb + fb0[1]);
-    }
-    static_for<0, 3>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      constexpr bool two = c < 2;                              // the half chunk carries one fragment per wave
-      static_for<0, NKA>([&](auto ktc) {
-        constexpr int kt = decltype(ktc)::value;
-        constexpr bool last = c == 2 && kt == NKA - 1;         // last stage of the super-chunk: nothing to prefetch
-        constexpr bool next_two = kt == NKA - 1 ? c + 1 < 2 : two;
-        const unsigned sb = lds0 + slot * SLOT;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          const int cur = kk & 1, nxt = cur ^ 1;
-          if (kk + 1 < KK) {
-            fb[nxt][0] = lds_read_frag(sb + (fb0[0] ^ ((kk + 1) << 5)));
-            if constexpr (two) { fb[nxt][1] = lds_read_frag(sb + (fb0[1] ^ ((kk + 1) << 5))); astat_wait_b<2>(fb[cur][0], fb[cur][1]); }
-            else astat_wait_b<1>(fb[cur][0], fb[cur][1]);
-          } else {
-            astat_wait_b<0>(fb[cur][0], fb[cur][1]);           // every read of this stage by this wave is done
-            if constexpr (!last) {
-              ++s;
-              slot = slot == NSLOT - 1 ? 0 : slot + 1;
-              stage_begin();
-              const unsigned sn = lds0 + slot * SLOT;
-              fb[nxt][0] = lds_read_frag(sn + fb0[0]);
-              if constexpr (next_two) fb[nxt][1] = lds_read_frag(sn + fb0[1]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          acc[2 * c] = H16<FL>::mfma(afr[kt][kk], fb[cur][0], acc[2 * c]);
-          if constexpr (two) acc[2 * c + 1] = H16<FL>::mfma(afr[kt][kk], fb[cur][1], acc[2 * c + 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
-    });
-    ++s;
-    slot = slot == NSLOT - 1 ? 0 : slot + 1;
-    // ---- epilogue of the super-chunk: each wave stages and writes its own five 32 x 32 fragments (no block barrier: the ring keeps landing)
-    static_for<0, NF>([&](auto fc) {
-      constexpr int f = decltype(fc)::value;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + l31] = acc[f][r];
-      epilogue_slab<FL, 32, SLD, EPI_PLAIN>(p, C, R, reinterpret_cast<const float*>(smem + NSLOT * SLOT), wave, lane, m0 + wy * 32,
-                                            sc * SCW + (f >> 1) * 128 + (f & 1) * 64, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-    });
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 template <int BM, int BN, int S, int WAVES, int FL>
 static void launch_ring64_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
@@ -529,27 +358,6 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);
   else launch_ring64_t<128, 128, 3>(a, tiles(128, 128), st);
-  DPB_CHECK(hipGetLastError());
-  return 0;
-}
-
-// tile code 530: the A-stationary short-K kernel
-int gemm_astat_supported(const GemmArgs& a) {
-  return a.gather == GATHER_NONE && !a.A2 && a.zeros && a.epi == EPI_PLAIN && a.K % 64 == 0 && a.K >= 64 && a.K <= 320 && a.N % 320 == 0 && a.M >= 128 &&
-         a.lda % 8 == 0 && a.ldb % 8 == 0;
-}
-int launch_gemm_astat(const GemmArgs& a, hipStream_t st) {
-  if (!gemm_astat_supported(a) || a.splitk > 1) { set_error("gemm: the A-stationary kernel takes plain rows, K = 64..320, N %% 320 == 0, no split"); return -1; }
-  const dim3 g((a.M + 127) / 128, a.Z1 * a.Z2);
-#define DPB_ASTAT(NKAV) do { if (a.fl) hipLaunchKernelGGL((gemm_astat_kernel<NKAV, 1>), g, dim3(512), 0, st, a); else hipLaunchKernelGGL((gemm_astat_kernel<NKAV, 0>), g, dim3(512), 0, st, a); } while (0)
-  switch (a.K / 64) {
-    case 1: DPB_ASTAT(1); break;
-    case 2: DPB_ASTAT(2); break;
-    case 3: DPB_ASTAT(3); break;
-    case 4: DPB_ASTAT(4); break;
-    default: DPB_ASTAT(5); break;
-  }
-#undef DPB_ASTAT
   DPB_CHECK(hipGetLastError());
   return 0;
 }

@@ -58,8 +58,6 @@ int gemm_uses_big_tile(int dtype, const GemmArgs& a);
 void gemm_debug_set(int tile, int splitk, int kch);
 int gemm_kch(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st);   // bf16, single operand pair, no split-K (gemm_dma.hip); tile 128 | 64 | 66 (64 with a 6-stage ring)
-int gemm_astat_supported(const GemmArgs& a);                    // the A-stationary short-K kernel (tile code 530, gemm_ring64.hip) takes this product
-int launch_gemm_astat(const GemmArgs& a, hipStream_t st);
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st);   // BK = 64 ring (gemm_ring64.hip); tile 512 | 513 | 514 | 515
 int conv_halo_supported(const GemmArgs& a);                        // 3x3 stride-1 convolution in halo-tile form (gemm_halo.hip)
 int launch_conv_halo(const GemmArgs& a, hipStream_t st);
