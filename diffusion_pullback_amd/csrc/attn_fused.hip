@@ -187,7 +187,9 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int b = blk.y / a.H, h = blk.y % a.H;
-  const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const int q_ = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const bool live = q_ < a.L;                 // short sequences (L < the block's rows): whole waves past the end compute on a clamped row and store nothing
+  const int q = live ? q_ : a.L - 1;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
     }
   }
   const float il = 1.f / l;
-  if (lhi == 0) {
+  if (lhi == 0 && live) {
     float* st = stats_out + (((long)b * a.H + h) * a.L + q) * 2;
     st[0] = m * 0.69314718055994531f;                     // natural-log units: max of the scaled scores
     st[1] = il;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = d * 32 + 8 * g + 4 * lhi;
-      if (col < D) {
+      if (col < D && live) {
         *reinterpret_cast<uint2*>(Op + col) = make_uint2(H16<FL>::pack2(acc[d][g * 4] * il, acc[d][g * 4 + 1] * il),
                                                          H16<FL>::pack2(acc[d][g * 4 + 2] * il, acc[d][g * 4 + 3] * il));
       }
@@ -270,7 +272,9 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
-  const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const int q_ = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const bool live = q_ < a.L;                 // short sequences (L < the block's rows): whole waves past the end compute on a clamped row and store nothing
+  const int q = live ? q_ : a.L - 1;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
   const bf16* Kp = a.K + b * LC + h * D;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = d * 32 + 8 * g + 4 * lhi;
-      if (col < D) {
+      if (col < D && live) {
         uint2 ov = *reinterpret_cast<const uint2*>(Op + col);
         unsigned ow[2] = {ov.x, ov.y};
         unsigned w[2];
@@ -412,7 +416,9 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
-  const int q = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const int q_ = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const bool live = q_ < a.L;                 // short sequences (L < the block's rows): whole waves past the end compute on a clamped row and store nothing
+  const int q = live ? q_ : a.L - 1;
   const long LC = (long)a.L * a.C;
   const bf16* Kp = a.K + b * LC + h * D;
   const bf16* Vp = a.V + b * LC + h * D;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = d * 32 + 8 * g + 4 * lhi;
-      if (col < D) {
+      if (col < D && live) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = a.scale * acc[d][g * 4 + i];
@@ -636,7 +642,9 @@ __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const BlockXY blk = xcd_group_blocks(a.xcd);
   const int j = blk.y / a.H, h = blk.y % a.H, b = j / a.kps;
-  const int key = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const int key_ = blk.x * (F::WAVES * 32) + wave * 32 + l31;
+  const bool live = key_ < a.L;               // short sequences: whole waves past the end compute on a clamped row and store nothing
+  const int key = live ? key_ : a.L - 1;
   const long LC = (long)a.L * a.C;
   const bf16* Qp = a.Q + b * LC + h * D;
   const long LCo = (long)a.L * a.Co;
@@ -717,7 +725,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = d * 32 + 8 * g + 4 * lhi;
-      if (col < D) {
+      if (col < D && live) {
         float vk[4], vv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { vk[i] = a.scale * accK[d][g * 4 + i]; vv[i] = accV[d][g * 4 + i]; }
@@ -1168,7 +1176,9 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16* S, float* st
 }
 
 int fused_attention_supported(int dtype, int d, int L, int kv_const) {
-  return dtype != DT_F32 && !kv_const && head_dim_ok(d) && L >= 256 && L % (att_waves(d) * 32) == 0;
+  // L >= 256 in whole blocks; or the one-stage case L = 64 at head dim 160 (the 8x8 level of SD-1.x: one 64-key stage, half of the block's waves idle) --
+  // three launches per iteration instead of the materialised path's ~19 tiny ones
+  return dtype != DT_F32 && !kv_const && head_dim_ok(d) && ((L >= 256 && L % (att_waves(d) * 32) == 0) || (d == 160 && L == 64));
 }
 
 int launch_row_stats(int fl, const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st) {
@@ -1194,7 +1204,7 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
 
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / (att_waves(f.d) * 32), batch * f.H);
+  dim3 grid((f.L + att_waves(f.d) * 32 - 1) / (att_waves(f.d) * 32), batch * f.H);
   if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_fwd_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a, (bf16*)O, stats));
   DPB_CHECK(hipGetLastError());
@@ -1222,7 +1232,7 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
     DPB_CHECK(hipGetLastError());
     return 0;
   }
-  dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
+  dim3 grid((f.L + att_waves(f.d) * 32 - 1) / (att_waves(f.d) * 32), nt * f.H);
   DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_jvp_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   DPB_CHECK(hipGetLastError());
   return 0;
@@ -1232,7 +1242,7 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
 // measured in round 2: both kernels hold a CU's LDS alone, so they time-slice instead of overlapping: 587 us for the pair vs 585 us back to back.)
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   FusedArgs a = to_args(f);
-  dim3 grid(f.L / (att_waves(f.d) * 32), nt * f.H);
+  dim3 grid((f.L + att_waves(f.d) * 32 - 1) / (att_waves(f.d) * 32), nt * f.H);
   static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernel (tuning switch)
   if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   // The shared-probability adjoint kernels serve head dim 40 (the SD-1.x 64x64 level).  They are instantiated for d = 64 too (SD-2.x: every level), but

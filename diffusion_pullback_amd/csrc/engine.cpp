@@ -841,7 +841,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
       const size_t H = p.heads;
       // long bf16 self-attention layers run the flash-style kernels (attn_fused.hip): no L x L object is ever stored
       p.fused = !p.causal && fused_attention_supported(e->dtype, p.d, p.Lq, p.kv_const) && !getenv("DPB_NO_FUSED_ATTN") &&
-                p.Lq >= (getenv("DPB_FUSED_ATTN_MIN_L") ? atoi(getenv("DPB_FUSED_ATTN_MIN_L")) : 256) &&      // tuning override
+                p.Lq >= (getenv("DPB_FUSED_ATTN_MIN_L") ? atoi(getenv("DPB_FUSED_ATTN_MIN_L")) : 64) &&       // tuning override (256: the 8x8 level back on the materialised path)
                 e->bufs[d.in0].C == e->bufs[d.in1].C && e->bufs[d.in0].C == e->bufs[d.in2].C;
       p.cross = !p.causal && cross_attention_supported(e->dtype, p.d, p.Lq, p.Lk, p.kv_const) && !getenv("DPB_NO_CROSS_ATTN") &&
                 e->bufs[d.in1].C == e->bufs[d.in2].C;

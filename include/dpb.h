@@ -168,8 +168,9 @@ int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms
  * LayerNorm leaves its fp32 slabs to that kernel instead of running splitk_reduce_kernel; 0 = always reduce; bitwise the same results).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
  * kernel and split count per product shape; DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
- * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L, DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN,
- * DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants. */
+ * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_LN_FUSE, DPB_LAZY_REDUCE, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_SHARED, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L,
+ * DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN, DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants; DPB_GEMM_TRACE=1 prints every
+ * product and synchronises after it (debugging). */
 int dpb_debug_set(const char* key, int value);
 
 /* Host-only (no GPU work): the launch plan the GEMM dispatch picks for a product C[M][N] = A[M][K] B[N][K]^T -- plain rows (conv_hw = 0) or

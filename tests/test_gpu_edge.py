@@ -174,6 +174,41 @@ def test_shared_probability_attention_kernels_match_per_tangent_kernels(dtype, h
         L.check(lib.dpb_debug_set(b"attn_shared", 2))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_short_sequence_fused_attention_matches_the_materialised_path(dtype, monkeypatch):
+    """L = 64 keys at head dim 160 (the 8x8 level of SD-1.x) runs the flash-style kernels with one 64-key stage and half of each block's waves
+    past the end of the sequence (clamped rows, no stores): primal, tangent and adjoint against the materialised path (scores in HBM) that
+    DPB_FUSED_ATTN_MIN_L=256 selects, one and two samples, k = 5 and a ragged k = 3."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    cfg = unet_sd.SDConfig(block_out_channels=(1280,), layers_per_block=1, down_attn=(True,), up_attn=(True,), heads=(8,), cross_dim=768,
+                           sample_size=8, ctx_len=77)                     # 8x8 tokens = 64, 8 heads of 160
+    p = unet_sd.init_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(2, 4, 8, 8, generator=g); ctx = torch.randn(2, 77, 768, generator=g)
+    tap = ("mid", 0)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    nets = {}
+    for name, min_l in (("materialised", "256"), ("fused", "64")):
+        monkeypatch.setenv("DPB_FUSED_ATTN_MIN_L", min_l)
+        nets[name] = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=2, max_rank=10, upto=tap, verbose=False)
+    monkeypatch.delenv("DPB_FUSED_ATTN_MIN_L")
+    for B, k in [(1, 5), (2, 5), (1, 3)]:
+        V = torch.randn(B * k, 4 * 8 * 8, generator=g)
+        U = torch.randn(B * k, nets["fused"].engine.tap_numel(tap), generator=g)
+        out = {}
+        for name, net in nets.items():
+            e = net.engine
+            e.primal(z[:B], 696.2727, ctx[:B], tap)
+            out[name] = (e.read(tap).clone(), e.jvp(tap, V).clone(), e.vjp(tap, U).clone())
+        for a, b in zip(out["materialised"], out["fused"]):
+            assert torch.isfinite(b).all()
+            assert rel(b, a) < tol, (B, k, rel(b, a))
+    n_fused = nets["fused"].engine.stats()[0]
+    n_mat = nets["materialised"].engine.stats()[0]
+    assert n_fused < n_mat, (n_fused, n_mat)                              # launches of the last pass (the adjoint)
+
+
 def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
     """Split-K products whose consumer is a one-launch GroupNorm or a LayerNorm leave their fp32 slabs to that kernel (no splitk_reduce_kernel launch,
     no 16-bit round trip of the tensor unless another op reads it).  The consumer adds the slabs in slab order, adds the residual and rounds exactly
