@@ -165,6 +165,7 @@ struct FusedArgs {
   const bf16 *KT, *VT, *QT;           // primal per-head transposes [B][H][d][L]
   const float* stats;                 // primal row statistics [B][H][L][2] = (m, 1/l) of the scaled scores
   float* Drow;                        // scratch [nt][H][L]: D = gO . O per (cotangent, head, query) (shared-P key-major adjoint)
+  float* Dout;                        // attn_adj_q_multi_kernel: where to leave its D_t (= Drow when the key-major shared kernel runs next), or nullptr
   const bf16 *dQ, *dK, *dV, *dVT;     // tangent inputs [nt][L][C], dV^T [nt][H][d][L]
   bf16* dO;                           // tangent output [nt][L][C]
   const bf16 *gO, *gOT;               // cotangent of the output [nt][L][C], gO^T [nt][H][d][L]
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
           for (int e = 0; e < 8; ++e) Dq[t] += H16<FL>::up(g16[e]) * H16<FL>::up(o16[e]);
         }
         Dq[t] += __shfl_xor(Dq[t], 32, 64);
+        if (a.Dout && lhi == 0) a.Dout[((long)(j0 + t) * a.H + h) * a.L + q] = Dq[t];   // D_t for the key-major kernel launched next (no row-dot pre-pass)
       } else {
 #pragma unroll
         for (int stp = 0; stp < F::NS; ++stp) gof[t][stp] = bf16x8{};
@@ -1194,7 +1196,7 @@ static FusedArgs to_args(const FusedAttnArgs& f) {
   FusedArgs a;
   a.xcd = attn_xcd_on();
   a.Q = (const bf16*)f.Q; a.K = (const bf16*)f.K; a.V = (const bf16*)f.V; a.O = (const bf16*)f.O;
-  a.KT = (const bf16*)f.KT; a.VT = (const bf16*)f.VT; a.QT = (const bf16*)f.QT; a.stats = f.stats; a.Drow = f.Drow;
+  a.KT = (const bf16*)f.KT; a.VT = (const bf16*)f.VT; a.QT = (const bf16*)f.QT; a.stats = f.stats; a.Drow = f.Drow; a.Dout = nullptr;
   a.dQ = (const bf16*)f.dQ; a.dK = (const bf16*)f.dK; a.dV = (const bf16*)f.dV; a.dVT = (const bf16*)f.dVT; a.dO = (bf16*)f.dO;
   a.gO = (const bf16*)f.gO; a.gOT = (const bf16*)f.gOT; a.gQ = (bf16*)f.gQ; a.gK = (bf16*)f.gK; a.gV = (bf16*)f.gV;
   a.accQ = f.accQ; a.accK = f.accK; a.accV = f.accV;
@@ -1240,21 +1242,33 @@ int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
 
 // (Running the query-major kernel (gQ) on a side stream next to the key-major kernel (gK, gV) -- they write disjoint column windows -- was
 // measured in round 2: both kernels hold a CU's LDS alone, so they time-slice instead of overlapping: 587 us for the pair vs 585 us back to back.)
-int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
-  FusedArgs a = to_args(f);
-  dim3 grid((f.L + att_waves(f.d) * 32 - 1) / (att_waves(f.d) * 32), nt * f.H);
+// which kernels the adjoint of one fused layer takes: bit 0 multi-cotangent query-major kernel, bit 1 shared-probability key-major kernel
+static int attn_adj_route(int d, int L, int kps, int nt, bool have_drow) {
   static const int multi = getenv("DPB_ATTN_MULTI") ? atoi(getenv("DPB_ATTN_MULTI")) : 1;   // shared-P multi-cotangent kernel (tuning switch)
-  if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
   // The shared-probability adjoint kernels serve head dim 40 (the SD-1.x 64x64 level).  They are instantiated for d = 64 too (SD-2.x: every level), but
   // there they measured no gain -- SD-2.1-base mid, k = 5, fp16: 8.41 ms per iteration on the per-cotangent kernels, 8.43 with the query-major one,
   // 8.54 with both (5 heads at L = 4096 give the key-major kernel 320 blocks = 1.25 rounds of one block per CU) -- so d = 64 takes them only when
   // bit 2 of the attn_shared switch asks (the parity test does).
   const int shared = g_attn_shared;
-  const bool dsh = f.d == 40 || (f.d == 64 && (shared & 4));
-  if (dsh && (multi & 1) && f.L % 128 == 0 && nt % f.kps == 0) {
+  const bool dsh = d == 40 || (d == 64 && (shared & 4));
+  int r = 0;
+  if (dsh && (multi & 1) && L % 128 == 0 && nt % kps == 0) r |= 1;
+  if (dsh && (shared & 2) && L % 64 == 0 && kps >= 4 && nt % kps == 0 && have_drow) r |= 2;
+  return r;
+}
+// launches of launch_attn_adj_fused: query-major + key-major (+ the row-dot pre-pass when the key-major shared kernel cannot take D_t from the multi-cotangent one)
+int attn_adj_launches(int d, int L, int kps, int nt) { const int r = attn_adj_route(d, L, kps, nt, true); return 2 + (r == 2); }
+
+int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
+  FusedArgs a = to_args(f);
+  dim3 grid((f.L + att_waves(f.d) * 32 - 1) / (att_waves(f.d) * 32), nt * f.H);
+  if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  const int route = attn_adj_route(f.d, f.L, f.kps, nt, f.Drow != nullptr);
+  if (route & 1) {
     constexpr int TJ = 5;
     const int ngrp = (f.kps + TJ - 1) / TJ;
     const dim3 gq(f.L / 128, (nt / f.kps) * f.H * ngrp);
+    if (route & 2) a.Dout = a.Drow;               // the row dots D_t = gO_t . O it computes anyway, left for the key-major kernel
 #define DPB_ADJQ(DV, FLV) hipLaunchKernelGGL((attn_adj_q_multi_kernel<DV, TJ, FLV>), gq, dim3(256), 0, st, a)
     if (f.d == 40) { if (f.fl) DPB_ADJQ(40, 1); else DPB_ADJQ(40, 0); }
     else { if (f.fl) DPB_ADJQ(64, 1); else DPB_ADJQ(64, 0); }
@@ -1262,15 +1276,15 @@ int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {
   } else {
     DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_adj_q_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a));
   }
-  if (dsh && (shared & 2) && f.L % 64 == 0 && f.kps >= 4 && nt % f.kps == 0 && f.Drow) {
+  if (route & 2) {
     constexpr int TJ = 5;
     const int ngrp = (f.kps + TJ - 1) / TJ;
     const dim3 gs(f.L / 64, (nt / f.kps) * f.H * ngrp);
     const unsigned nrd = (unsigned)(((long)nt * f.L * f.H + 255) / 256);
-#define DPB_ADJKV(DV, FLV)                                                                                   \
-    do {                                                                                                       \
-      hipLaunchKernelGGL((attn_rowdot_kernel<DV, FLV>), dim3(nrd), dim3(256), 0, st, a, nt);                  \
-      hipLaunchKernelGGL((attn_adj_kv_shared_kernel<DV, TJ, FLV>), gs, dim3(SHK<DV, TJ>::NT), 0, st, a);      \
+#define DPB_ADJKV(DV, FLV)                                                                                                          \
+    do {                                                                                                                              \
+      if (!(route & 1)) hipLaunchKernelGGL((attn_rowdot_kernel<DV, FLV>), dim3(nrd), dim3(256), 0, st, a, nt);                       \
+      hipLaunchKernelGGL((attn_adj_kv_shared_kernel<DV, TJ, FLV>), gs, dim3(SHK<DV, TJ>::NT), 0, st, a);                             \
     } while (0)
     if (f.d == 40) { if (f.fl) DPB_ADJKV(40, 1); else DPB_ADJKV(40, 0); }
     else { if (f.fl) DPB_ADJKV(64, 1); else DPB_ADJKV(64, 0); }

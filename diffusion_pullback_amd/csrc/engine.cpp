@@ -603,7 +603,7 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
   // first-write / accumulate flags, read up front: q, k, v may be windows of ONE buffer (fused QKV)
   const int accQ = e->ginit[d.in0], accK = p.kv_const ? 0 : e->ginit[d.in1], accV = p.kv_const ? 0 : e->ginit[d.in2];
   if (p.fused) {
-    e->n_launch += 2 + (p.d == 40 && kps >= 4);   // (+ the row-dot kernel of the shared-P key-major adjoint)
+    e->n_launch += attn_adj_launches(p.d, p.Lq, kps, nt);
     FusedAttnArgs f;
     fill_fused(e, p, x, f, kps, scale);
     f.gO = gO; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V; f.Drow = Dv;

@@ -64,7 +64,18 @@ __global__ __launch_bounds__(64) void eig_kernel(const double* Gp, int nbg, doub
   const int r = threadIdx.x;
   for (int e = r; e < k * k; e += 64) {          // Gram matrix and overlaps: the blocks' partials added in block order
     double g = 0.0, x = 0.0;
-    for (int b = 0; b < nbg; ++b) { g += Gp[((long)b * 2) * k * k + e]; x += Gp[((long)b * 2 + 1) * k * k + e]; }
+    for (int b0 = 0; b0 < nbg; b0 += 8) {        // eight partials of each in flight (clamped loads), then added in order
+      double tg[8], tx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long b = min(b0 + u, nbg - 1);
+        tg[u] = Gp[(b * 2) * k * k + e];
+        tx[u] = Gp[(b * 2 + 1) * k * k + e];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + u < nbg) { g += tg[u]; x += tx[u]; }
+    }
     Q[e / k][e % k] = g;
     X[e] = x;
   }
@@ -171,13 +182,22 @@ __global__ __launch_bounds__(256) void orth_apply_kernel(const float* W, const f
 
 __global__ void orth_finish_kernel(const double* acc, int nb, float* conv) {
   double d2 = 0.0, m = 0.0;
-  for (int b = 0; b < nb; ++b) { d2 += acc[2 * b]; m = fmax(m, acc[2 * b + 1]); }
+  for (int b0 = 0; b0 < nb; b0 += 16) {          // sixteen partial pairs in flight, added in block order
+    double t[16], v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int b = min(b0 + u, nb - 1); t[u] = acc[2 * b]; v[u] = acc[2 * b + 1]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (b0 + u < nb) { d2 += t[u]; m = fmax(m, v[u]); }
+  }
   conv[0] = (float)sqrt(d2);
   conv[1] = (float)m;
 }
 
-static inline unsigned orth_nb(long N) { unsigned nb = (unsigned)((N + 2047) / 2048); return nb > 512 ? 512 : (nb < 1 ? 1 : nb); }
-static inline unsigned orth_nbg(long N) { const unsigned nb = orth_nb(N); return nb > 32 ? 32 : nb; }
+// blocks of the streaming passes: one 256-column slice per block up to 256 blocks (a 4 x 64 x 64 latent: 64 blocks, one load round per thread -- with 2048
+// columns per block the eight dependent rounds of a thread made each pass 22 us of pure latency), beyond that a grid-stride loop
+static inline unsigned orth_nb(long N) { unsigned nb = (unsigned)((N + 255) / 256); return nb > 256 ? 256 : (nb < 1 ? 1 : nb); }
+static inline unsigned orth_nbg(long N) { const unsigned nb = orth_nb(N); return nb > 64 ? 64 : nb; }
 size_t orth_scratch_bytes(int k, long N) {     // Cm [k][k] | Gram partials [nbg][2][k][k] | (dist^2, violation) partials [nb][2]
   return sizeof(double) * ((size_t)k * k * (1 + 2 * orth_nbg(N)) + 2 * (size_t)orth_nb(N));
 }
