@@ -176,18 +176,20 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
     }
     return;
   }
-  constexpr int ITEMS = 32 * CPR / 64;
+  // item it of a lane = row it * RPI + lane / CPR of the staged slab, 16-byte column lane % CPR: the column is the same for every item of a lane
+  constexpr int ITEMS = 32 * CPR / 64, RPI = 64 / CPR;
+  static_assert(64 % CPR == 0, "a lane keeps its column across items");
+  const int c8 = lane % CPR, r0 = lane / CPR;
+  const int n = n0 + wx * WN + c8 * 8;
+  if (n >= p.N) return;
+  if (EPI == EPI_PLAIN && p.splitk > 1) {         // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel (or by the consumer: SlabSrc)
 #pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int item = it * 64 + lane;
-    const int row = item / CPR, c8 = item % CPR;
-    const int m = mrow0 + row;
-    const int n = n0 + wx * WN + c8 * 8;
-    if (m >= p.M || n >= p.N) continue;
-    float v[8];
-    Vec<float>::load(stage + row * SLD + c8 * 8, v);
-    Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
-    if (EPI == EPI_PLAIN && p.splitk > 1) {       // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
+    for (int it = 0; it < ITEMS; ++it) {
+      const int row = it * RPI + r0, m = mrow0 + row;
+      if (m >= p.M) continue;
+      float v[8];
+      Vec<float>::load(stage + row * SLD + c8 * 8, v);
+      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
       float* sp = p.slab + slab_idx * (long)p.M * p.N + (long)m * p.N + n;
       if (n + 8 <= p.N && !(p.N & 3)) {
         Vec<float>::store(sp, v);
@@ -195,9 +197,17 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) sp[e] = v[e];
       }
-      continue;
     }
-    if constexpr (EPI == EPI_GEGLU_ADJ) {                 // v = gy of hidden units n..n+7 (n % 8 == 0, N = F % 64 == 0)
+    return;
+  }
+  if constexpr (EPI == EPI_GEGLU_ADJ) {           // v = gy of hidden units n..n+7 (n % 8 == 0, N = F % 64 == 0)
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int row = it * RPI + r0, m = mrow0 + row;
+      if (m >= p.M) continue;
+      float v[8];
+      Vec<float>::load(stage + row * SLD + c8 * 8, v);
+      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
       const int F2 = 2 * p.N;
       const int ni = ((n >> 6) << 7) + (n & 63);   // interleaved column of a; g sits 64 further
       const int smp = m / p.rows_per_sample, l = m - smp * p.rows_per_sample;
@@ -221,38 +231,70 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
       }
       H16<FL>::store8(cp, oa);
       H16<FL>::store8(cp + 64, og);
-      continue;
     }
-    int smp = 0;
-    if (p.rowbias) smp = (m / p.rows_per_sample) / p.rowbias_div;
-    bf16* cp = C + (long)m * p.ldc + n;
-    if (p.vec_ok && n + 8 <= p.N) {
+    return;
+  }
+  if (p.vec_ok && n + 8 <= p.N) {
+    // The operands of the epilogue (row bias, residual, the value accumulated so far) do not depend on the product: the loads of up to four items
+    // are issued together, at clamped rows, before anything waits -- one memory round trip per batch instead of one per operand and item (the
+    // item-by-item form cost a 64x64-level product with a residual ~5 us of dependent L2 round trips).  Same additions in the same order.
+    float b8[8];
+    if (p.bias) {
+      Vec<float>::load(p.bias + n, b8);
+      Vec<float>::load(p.bias + n + 4, b8 + 4);
+    }
+    constexpr int BT = ITEMS > 4 ? 4 : ITEMS;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-      float b8[8];
-      if (p.bias) {
-        Vec<float>::load(p.bias + n, b8);
-        Vec<float>::load(p.bias + n + 4, b8 + 4);
+    for (int it0 = 0; it0 < ITEMS; it0 += BT) {
+      uint4 rr[BT], ro[BT], rb[BT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      for (int u = 0; u < BT; ++u) {
+        const int mc = min(mrow0 + (it0 + u) * RPI + r0, p.M - 1);
+        if (R) rr[u] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + n);
+        if (p.accumulate) ro[u] = *reinterpret_cast<const uint4*>(C + (long)mc * p.ldc + n);
+        if (p.rowbias) rb[u] = *reinterpret_cast<const uint4*>((const bf16*)p.rowbias + (long)((mc / p.rows_per_sample) / p.rowbias_div) * p.N + n);
       }
-      if (p.rowbias) {
-        H16<FL>::load8((const bf16*)p.rowbias + (long)smp * p.N + n, b8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
-      }
-      if (R) {
-        H16<FL>::load8(R + (long)m * p.ldr + n, b8);
+      for (int u = 0; u < BT; ++u) {
+        const int row = (it0 + u) * RPI + r0, m = mrow0 + row;
+        if (m >= p.M) continue;
+        float v[8], t8[8];
+        Vec<float>::load(stage + row * SLD + c8 * 8, v);
+        Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
-      }
-      if (p.accumulate) {
-        H16<FL>::load8(cp, b8);
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        if (p.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+          for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        }
+        if (p.rowbias) {
+          H16<FL>::load8(reinterpret_cast<const bf16*>(&rb[u]), t8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t8[e];
+        }
+        if (R) {
+          H16<FL>::load8(reinterpret_cast<const bf16*>(&rr[u]), t8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t8[e];
+        }
+        if (p.accumulate) {
+          H16<FL>::load8(reinterpret_cast<const bf16*>(&ro[u]), t8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t8[e];
+        }
+        H16<FL>::store8(C + (long)m * p.ldc + n, v);
       }
-      H16<FL>::store8(cp, v);
-    } else {
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int row = it * RPI + r0, m = mrow0 + row;
+      if (m >= p.M) continue;
+      float v[8];
+      Vec<float>::load(stage + row * SLD + c8 * 8, v);
+      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
+      const int smp = p.rowbias ? (m / p.rows_per_sample) / p.rowbias_div : 0;
+      bf16* cp = C + (long)m * p.ldc + n;
       for (int e = 0; e < 8 && n + e < p.N; ++e) {
         float x = p.alpha * v[e];
         if (p.bias) x += p.bias[n + e];

@@ -14,7 +14,7 @@
 // Halo pixel p of a buffer lives at p*128 B, chunk c at ((c ^ ((p >> 1) & 7)) * 16 B (same source-side swizzle as the
 // ring: conflict-free ds_read_b128 for runs of consecutive pixels); out-of-image pixels read the zero page.
 // The weight-ring / barrier / in-wave fragment-prefetch structure and the epilogue are those of gemm_ring64.hip.
-#include "kernels.h"
+#include "epilogue.h"
 
 namespace dpb {
 
@@ -217,9 +217,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- epilogue through LDS (same scheme as gemm_ring64.hip)
+  // ---- epilogue through LDS: the staging layout and the slab writer of the ring kernels (epilogue.h)
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
-  constexpr int CPR = WN / 8, ITEMS = 32 * CPR / 64;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -227,66 +226,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item / CPR, c8 = item % CPR;
-      const int m = m0 + wy * 64 + i * 32 + row;
-      const int n = n0 + wx * WN + c8 * 8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
-      Vec<float>::load(stage + row * SLD + c8 * 8, v);
-      Vec<float>::load(stage + row * SLD + c8 * 8 + 4, v + 4);
-      if (p.splitk > 1) {                           // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
-        float* sp = p.slab + (long)ksplit * (long)p.M * p.N + (long)m * p.N + n;
-        if (n + 8 <= p.N && !(p.N & 3)) {
-          Vec<float>::store(sp, v);
-          Vec<float>::store(sp + 4, v + 4);
-        } else {
-          for (int e = 0; e < 8 && n + e < p.N; ++e) sp[e] = v[e];
-        }
-        continue;
-      }
-      int smpb = 0;
-      if (p.rowbias) smpb = (m / p.rows_per_sample) / p.rowbias_div;
-      bf16* cp = C + (long)m * p.ldc + n;
-      if (p.vec_ok && n + 8 <= p.N) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-        float b8[8];
-        if (p.bias) {
-          Vec<float>::load(p.bias + n, b8);
-          Vec<float>::load(p.bias + n + 4, b8 + 4);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        if (p.rowbias) {
-          H16<FL>::load8((const bf16*)p.rowbias + (long)smpb * p.N + n, b8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        if (R) {
-          H16<FL>::load8(R + (long)m * p.ldr + n, b8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        if (p.accumulate) {
-          H16<FL>::load8(cp, b8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b8[e];
-        }
-        H16<FL>::store8(cp, v);
-      } else {
-        for (int e = 0; e < 8 && n + e < p.N; ++e) {
-          float x = p.alpha * v[e];
-          if (p.bias) x += p.bias[n + e];
-          if (p.rowbias) x += ld16<FL>((const bf16*)p.rowbias + (long)smpb * p.N + n + e);
-          if (R) x += ld16<FL>(R + (long)m * p.ldr + n + e);
-          if (p.accumulate) x += ld16<FL>(cp + e);
-          st16<FL>(cp + e, x);
-        }
-      }
-    }
+    epilogue_slab<FL, WN, SLD, EPI_PLAIN>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * 64 + i * 32, n0, (long)ksplit);
     __syncthreads();
   }
 }
