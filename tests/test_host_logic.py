@@ -302,3 +302,17 @@ def test_spectrum_for_tap_shapes_the_last_self_attention_of_the_prefix():
     b = cf.sd_init_params(cfg, seed=0, spectrum=cf.Spectrum(also=("down_blocks.0.attentions.0",)))
     changed = sorted(k for k in a if not torch.equal(a[k], b[k]))
     assert changed == ["down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight"]
+
+
+def test_orth_scratch_contract_follows_the_block_layout():
+    """dpb_orth_scratch_bytes (include/dpb.h) is the caller's side of the re-orthonormalisation's fixed-order reductions: Cm [k][k], Gram / overlap
+    partials of up to 64 column slices, (distance, violation) partials of up to 256 slices of 256 columns -- a pure host function (no GPU needed)."""
+    from diffusion_pullback_amd import lib as L
+    lib = L.load()
+    f = lambda k, n: int(lib.dpb_orth_scratch_bytes(k, n))
+    assert f(5, 4 * 64 * 64) == 8 * (25 * (1 + 2 * 64) + 2 * 64)            # 64 slices of 256 columns: the SD latent
+    assert f(5, 3 * 256 * 256) == 8 * (25 * (1 + 2 * 64) + 2 * 256)         # both block counts capped: the DDPM-256 image
+    assert f(3, 100) == 8 * (9 * (1 + 2 * 1) + 2 * 1)                       # one ragged slice
+    assert f(56, 4 * 64 * 64) == 8 * (56 * 56 * (1 + 2 * 64) + 2 * 64)      # the largest supported rank
+    assert f(57, 4 * 64 * 64) == 0 and f(0, 4 * 64 * 64) == 0 and f(5, 0) == 0
+    assert all(f(k, n) <= f(k, 2 * n) for k in (1, 5, 50) for n in (64, 1000, 16384, 100000))
