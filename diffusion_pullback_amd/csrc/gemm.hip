@@ -559,8 +559,10 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   const ShapeOverride* ov = g_force_splitk ? nullptr : find_override(a);
   if (g_force_splitk) s = g_force_splitk;
   else if (ov && ov->split) s = ov->split;
-  else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~512 blocks, >= 8 stages of 64 each
-    static const long target = getenv("DPB_SPLITK_TARGET") ? atol(getenv("DPB_SPLITK_TARGET")) : 512;   // tuning switch
+  else if (tile >= 512) {                     // 2 resident blocks per CU: aim at ~450 blocks, >= 8 stages of 64 each
+    // (512 until the deferred reductions moved the slab gathers into the consumers: 448 / 384 measure 0.5 % ahead of 512 there, 320 / 256 behind;
+    // 768: +4 % -- profiles/r03_ab_sessions.txt)
+    static const long target = getenv("DPB_SPLITK_TARGET") ? atol(getenv("DPB_SPLITK_TARGET")) : 448;   // tuning switch
     // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
     // profiles/r02_gemm_split_microbench.txt (5120x640: K 1920 / 2560 24 / 32 us unsplit vs 34 / 41 us three-fold, K 5120 52 us two-fold vs
     // 58 unsplit; 1280x3840x1280 25 vs 36 us; 320x10240x1280 18 vs 25 us)
