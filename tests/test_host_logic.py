@@ -316,3 +316,13 @@ def test_orth_scratch_contract_follows_the_block_layout():
     assert f(56, 4 * 64 * 64) == 8 * (56 * 56 * (1 + 2 * 64) + 2 * 64)      # the largest supported rank
     assert f(57, 4 * 64 * 64) == 0 and f(0, 4 * 64 * 64) == 0 and f(5, 0) == 0
     assert all(f(k, n) <= f(k, 2 * n) for k in (1, 5, 50) for n in (64, 1000, 16384, 100000))
+
+
+def test_measurement_scripts_compile():
+    """tools/*.py and bench.py are not imported by any test (they need a GPU box): at least their syntax is checked here."""
+    import glob, os, py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.path.join("/tmp", "dpb_pyc_" + os.path.basename(f) + "c"))
