@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 
 ITERS_PER_SAMPLE = 12
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # TFLOP/s dense MFMA (MI355X_MICROARCH.md)
-MAC_G = {"sd15": 130.72, "ddpm256": 67.58}                 # GMAC of one get_h(mid) forward
+MAC_G = {"sd15": 130.72, "ddpm256": 67.58, "sd21": 130.72}   # GMAC of one get_h(mid) forward; SD-2.1-base: the same
+                                                             # linear maps except the text K / V projections (1024- instead of 768-wide, x-independent)
 TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
@@ -44,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="sd15", choices=["sd15", "ddpm256", "toy"])
+    ap.add_argument("--workload", default="sd15", choices=["sd15", "sd21", "ddpm256", "toy"],
+                    help="sd15: BASELINE configs[2..4] (headline); sd21: stabilityai/stable-diffusion-2-1-base, the reference scripts' own default model")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--op", default="mid", choices=["down", "mid", "up"], help="feature tap (BASELINE configs[4] sweeps down/up 0..3)")
@@ -61,12 +63,13 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU power iterations after the warm-up (BASELINE.md section 3: 2)")
     ap.add_argument("--repeats", type=int, default=7, help="the timed region of exactly --steps steps is run this many times; value = steps / MEDIAN time")
     ap.add_argument("--no-unet-forward", action="store_true", help="skip the DDIM-loop leg (full SD-1.5 U-Net forwards at B = 1 / 2 / 5)")
+    ap.add_argument("--no-sd21-leg", action="store_true", help="skip the SD-2.1-base k = 2 leg (the setting of the reference's only published timing)")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the BASELINE configs[3] leg (64 samples, k = 10, edit ctx, sharded over the ranks)")
     ap.add_argument("--strong-samples", type=int, default=64)
     ap.add_argument("--profile-run", action="store_true", help="for rocprofv3 runs: headline region only, once (no repeats, no extra legs, no CPU baseline)")
     a = ap.parse_args()
     if a.profile_run:
-        a.repeats, a.no_cpu_baseline, a.no_roofline, a.no_unet_forward, a.no_strong_leg = 1, True, True, True, True
+        a.repeats, a.no_cpu_baseline, a.no_roofline, a.no_unet_forward, a.no_strong_leg, a.no_sd21_leg = 1, True, True, True, True, True
     return a
 
 
@@ -76,9 +79,10 @@ def make_workload(name, dtype, device, k, spg, tap=("mid", 0), ctx_kind="null", 
     from diffusion_pullback_amd import configs as cf
     g = torch.Generator().manual_seed(0)
     sp = cf.Spectrum() if shaped else None
-    if name == "sd15" or name == "toy":
-        cfg = cf.SD15 if name == "sd15" else cf.SDConfig(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False),
-                                                          up_attn=(False, True), heads=(2, 2), cross_dim=64, sample_size=16, ctx_len=77)
+    if name in ("sd15", "sd21", "toy"):
+        toy = dict(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(2, 2), cross_dim=64,
+                   sample_size=16, ctx_len=77)
+        cfg = cf.SD15 if name == "sd15" else cf.sd_config_for("stabilityai/stable-diffusion-2-1-base") if name == "sd21" else cf.SDConfig(**toy)
         enc = ("time_embedding", "conv_in", "down_blocks", "mid_block") if tap[0] != "up" else None
         params = cf.sd_init_params(cfg, seed=0, only_prefix=enc, spectrum=sp)
         net = PullbackUNet("sd", cfg, params, dtype=dtype, device=device, max_batch=spg, max_rank=k * spg, upto=tap, verbose=False)
@@ -88,9 +92,10 @@ def make_workload(name, dtype, device, k, spg, tap=("mid", 0), ctx_kind="null", 
             ctx = torch.randn(1, cfg.ctx_len, cfg.cross_dim, generator=torch.Generator().manual_seed(4242))
         shape = (cfg.in_channels, cfg.sample_size, cfg.sample_size)
 
-        def oracle_get_h(zb):      # cpu_baseline leg only
+        def oracle_get_h(zb):      # cpu_baseline leg only; the oracle walks the seeded values with its OWN config and shape table
             from oracle import unet_sd
-            return unet_sd.forward(params, cfg, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=tap)
+            ocfg = unet_sd.SD15 if name == "sd15" else unet_sd.SD21_BASE if name == "sd21" else unet_sd.SDConfig(**toy)
+            return unet_sd.forward(params, ocfg, zb, torch.tensor(t), ctx.expand(zb.shape[0], -1, -1), stop=tap)
     else:
         cfg = cf.CELEBA_HQ_256
         params = cf.ddpm_init_params(cfg, seed=0, spectrum=sp)
@@ -113,6 +118,9 @@ def workload_name(a, strong, tap):
         return base + (", mid-block h[512,8,8]" if tap == ("mid", 0) else f", tap {tap[0]}{tap[1]} (not a BASELINE config)")
     if a.workload == "toy":
         return "toy SD-style net (plumbing check)"
+    if a.workload == "sd21":
+        return (f"stabilityai/stable-diffusion-2-1-base (the reference scripts' default model, not a BASELINE config): 4x64x64 latent, seeded ctx[1,77,1024], "
+                f"tap {tap[0]}_block_{tap[1]}, k={a.k}, t=696.27")
     if tap != ("mid", 0):
         return (f"BASELINE configs[4]: SD-v1.5 down/up-block sweep, tap {tap[0]}_block_{tap[1]}, 4x64x64 latent, seeded null ctx[1,77,768], t=696.27"
                 + ("" if a.k == 5 else f" (k={a.k}: BASELINE names k=5)"))
@@ -143,6 +151,23 @@ def pmc_traffic(dom, enabled):
                 f"HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{f}, same source hash {cur[:12]} as the running libdpb.so)"
     return None, (f"null: no committed PMC file was collected on this build (running libdpb.so source hash {cur[:12]}; candidates: {cands[:3]}) -- "
                   "re-run tools/pmc_mfma.sh + tools/collect_profiles.py after the last kernel change")
+
+
+def pmc_step_bytes(enabled):
+    """HBM bytes of ONE whole power iteration summed over every kernel of the committed PMC passes (same source-hash rule as pmc_traffic)."""
+    if not enabled:
+        return None, "no PMC passes are committed for this workload"
+    from diffusion_pullback_amd import lib as L
+    cur = L._built_hash()
+    for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_sd15_mid_k5_bf16.json")), reverse=True):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+        except (OSError, ValueError):
+            continue
+        if d.get("_src_hash") == cur and d.get("_whole_step_hbm_bytes"):
+            return float(d["_whole_step_hbm_bytes"]), (f"sum over all kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 per iteration, profiles/{f} "
+                                                       f"(same source hash {cur[:12]}); frac = bytes / ms_per_step / 8 TB/s")
+    return None, f"null: no committed PMC file with a whole-step sum was collected on this build ({cur[:12]})"
 
 
 def strong_leg(a, dev, dtype, dist, pdist, rank, world):
@@ -250,15 +275,38 @@ def unet_forward_leg(a, dev, dtype, dname, t, ctx, time_cpu):
         z1 = torch.randn(1, 4, 64, 64, generator=g)
         torch.set_num_threads(min(32, os.cpu_count() or 8))
         with torch.no_grad():
-            unet_sd.forward(params, cfg, z1, torch.tensor(t), ctx)
+            unet_sd.forward(params, unet_sd.SD15, z1, torch.tensor(t), ctx)
             tc = time.perf_counter()
             for _ in range(2):
-                unet_sd.forward(params, cfg, z1, torch.tensor(t), ctx)
+                unet_sd.forward(params, unet_sd.SD15, z1, torch.tensor(t), ctx)
             tcpu = (time.perf_counter() - tc) / 2
         out["cpu_oracle_forward"] = {"ms_per_forward": 1e3 * tcpu, "threads": torch.get_num_threads(), "kind": "port (oracle/unet_sd.py, fp32)", "batch": 1}
         out["speedup_vs_cpu_b1"] = tcpu / (out["batches"]["1"]["ms_per_forward"] * 1e-3)
     del net, eng
     torch.cuda.empty_cache()
+    return out
+
+
+def sd21_leg(dev):
+    """The reference's only published timing (example-code.ipynb:123-145): local_encoder_pullback_zt on stabilityai/stable-diffusion-2-1-base, mid block,
+    pca_rank 2, fp32, 12 iterations, 14.31 s on a Colab T4.  The same call here (synthetic weights at the exact shapes): wall seconds of primal + 12 iterations
+    through the reference-signature method (host loop, stop rule evaluated every iteration), fp32 and bf16 engines.  Context, not a same-node comparison."""
+    out = {"workload": "stabilityai/stable-diffusion-2-1-base U-Net, z[1,4,64,64], ctx[1,77,1024], mid block, pca_rank 2, 12 iterations "
+                       "(reference src/scripts/main_various_local_encoder_pullback_with_edit_prompt.sh:11; example-code.ipynb:123-145)",
+           "reference_published": {"seconds": 14.31, "hardware": "Colab T4, fp32 (example-code.ipynb:145 'power method runtime')", "iterations": 12}}
+    for dname in ("fp32", "bf16"):
+        net, _, shape, t, ctx, V0 = make_workload("sd21", TORCH_DTYPE[dname], dev, 2, 1, ("mid", 0), "null", True)
+        z = torch.randn(1, *shape, generator=torch.Generator().manual_seed(1000)).to(dev)
+        kw = dict(sample=z, timestep=t, encoder_hidden_states=ctx, op="mid", block_idx=0, pca_rank=2, min_iter=10, max_iter=12, convergence_threshold=0.0, V0=V0)
+        net.local_encoder_pullback_zt(**kw)                       # untimed: code objects, allocator
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        u, s_, vT = net.local_encoder_pullback_zt(**kw)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out["sd21_mid_k2_" + dname] = {"seconds": dt, "iterations": net.last_iters, "ms_per_iteration": 1e3 * dt / net.last_iters, "s": [round(v, 3) for v in s_.cpu().tolist()],
+                                       "finite": bool(torch.isfinite(vT).all()), "speedup_vs_published_t4": 14.31 / dt}
+        del net
+        torch.cuda.empty_cache()
     return out
 
 
@@ -395,7 +443,7 @@ def main():
 
     total_steps = steps if strong else world * steps
     res = {
-        "metric": "pullback top-k SVD iters/sec (SD-v1.5 mid-block, 4x64x64)" if a.workload == "sd15" else f"pullback top-k SVD iters/sec ({a.workload} mid-block)",
+        "metric": "pullback top-k SVD iters/sec (SD-v1.5 mid-block, 4x64x64)" if a.workload == "sd15" else "pullback top-k SVD iters/sec (SD-2.1-base mid-block, 4x64x64)" if a.workload == "sd21" else f"pullback top-k SVD iters/sec ({a.workload} mid-block)",
         "value": total_steps / dt, "unit": "iters/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / (steps if not strong else max(1, len(mine) * ITERS_PER_SAMPLE)), "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None,
@@ -438,24 +486,41 @@ def main():
                  "gemm_dma_kernel<128,128,3> / <256,128,3>": eng.profile_read(2), "gemm_dma_kernel<64,64,4>": eng.profile_read(3),
                  "gemm_ring64_kernel<128,128,2>": eng.profile_read(4), "conv_halo_kernel": eng.profile_read(5),
                  "gemm_ring64_kernel<256,256,2> (8 waves)": eng.profile_read(6)}
+        attn = {"attention forward (flash)": eng.profile_read(7), "attention tangent (attn_jvp_kernel)": eng.profile_read(8),
+                "attention adjoint (query-major + key-major launches)": eng.profile_read(9), "cross-attention tangent / adjoint (attn_cross_kernel)": eng.profile_read(10)}
         ovh_ms = eng.profile_overhead_ms()
         eng.profile(False)
         dom = max(kinds, key=lambda n: kinds[n][1])                      # dominant = most GPU time
-        n_d, ms_d, fl_d = kinds[dom]
+        n_d, ms_c, fl_d = kinds[dom]                                     # ms_c: bracket times minus the calibrated empty bracket
+        ms_d = ms_c + n_d * ovh_ms                                       # RAW event time: what the headline fraction is computed from
         ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
+        ach_corr = fl_d / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
         mac = MAC_G.get(a.workload) if tap == ("mid", 0) else None
         gemm_ms = sum(v[1] for v in kinds.values())
-        traffic, tnote = pmc_traffic(dom, a.workload == "sd15" and dname == "bf16" and S == 1 and k == 5 and tap == ("mid", 0))
+        headline_cfg = a.workload == "sd15" and dname == "bf16" and S == 1 and k == 5 and tap == ("mid", 0)
+        traffic, tnote = pmc_traffic(dom, headline_cfg)
+        step_bytes, snote = pmc_step_bytes(headline_cfg)
         ms_step = 1e3 * dt / (steps if not strong else max(1, len(mine) * ITERS_PER_SAMPLE))
+        raw = lambda v: v[1] + v[0] * ovh_ms
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach / PEAK[dname],
                            "traffic": traffic, "traffic_note": tnote,
                            "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
-                           "event_bracket_overhead_us": 1e3 * ovh_ms, "avg_launch_us_raw": 1e3 * ms_d / max(n_d, 1) + 1e3 * ovh_ms,
-                           "achieved_raw": fl_d / ((ms_d + n_d * ovh_ms) * 1e-3) / 1e12 if ms_d > 0 else 0.0,
-                           "timing_note": "HIP events around every launch on the engine stream; `achieved` subtracts a calibrated empty-bracket time per launch "
-                                          "(event_bracket_overhead_us), `achieved_raw` does not; the rocprofv3 kernel trace under profiles/ is the cross-check",
-                           "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * v[1] / max(v[0], 1),
-                                                    "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},
+                           "event_bracket_overhead_us": 1e3 * ovh_ms,
+                           "achieved_bracket_corrected": ach_corr, "frac_bracket_corrected": ach_corr / PEAK[dname],
+                           "avg_launch_us_bracket_corrected": 1e3 * ms_c / max(n_d, 1),
+                           "timing_note": "HIP events around every launch on the engine stream.  `achieved` / `frac` are the RAW event figures (flops / sum of bracket "
+                                          "times); `*_bracket_corrected` subtract a calibrated empty-bracket time per launch (event_bracket_overhead_us) and sit closer "
+                                          "to the rocprofv3 kernel trace under profiles/, which lies between the two",
+                           "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * raw(v) / max(v[0], 1),
+                                                    "achieved": v[2] / (raw(v) * 1e-3) / 1e12 if v[0] > 0 else 0.0,
+                                                    "achieved_bracket_corrected": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},
+                           "attention_kernels": {n: {"brackets": v[0], "avg_bracket_us": 1e3 * raw(v) / max(v[0], 1), "algorithmic_flops": v[2],
+                                                     "achieved": v[2] / (raw(v) * 1e-3) / 1e12 if v[0] > 0 else 0.0,
+                                                     "frac": v[2] / (raw(v) * 1e-3) / 1e12 / PEAK[dname] if v[0] > 0 else 0.0} for n, v in attn.items()},
+                           "attention_flops_note": "algorithmic L x L x d products per head: forward 2, tangent 5 per tangent, adjoint 7 per cotangent, cross-attention 2 "
+                                                   "(L x 77 x d); the shared-probability kernels do fewer MFMAs than that (P computed once per sample)",
+                           "whole_step_hbm_bytes": step_bytes, "whole_step_hbm_frac": (step_bytes / (ms_step * 1e-3) / 8e12) if step_bytes else None,
+                           "whole_step_hbm_note": snote,
                            "gemm_time_share_of_step": gemm_ms / (ms_step * S),
                            "algorithmic_flops_per_step": 2 * k * 2 * mac * 1e9 if mac else None,
                            "whole_step_frac_of_peak": (2 * k * 2 * mac * 1e9 / (ms_step * 1e-3) / 1e12 / PEAK[dname]) if mac else None,
@@ -504,6 +569,12 @@ def main():
         except Exception as ex:
             res["unet_forward"] = {"error": repr(ex)[:300]}
 
+    if rank == 0 and a.workload == "sd15" and not a.no_sd21_leg and not strong and tap == ("mid", 0) and S == 1 and k == 5:
+        try:
+            res["sd21_reference_setting"] = sd21_leg(dev)
+        except Exception as ex:
+            res["sd21_reference_setting"] = {"error": repr(ex)[:300]}
+
     if rank == 0 and not a.no_roofline and not strong and S == 1 and a.workload == "sd15":
         # ---- two independent samples in flight on two HIP streams (two engines over the SAME weights, own workspaces): what a per-sample job
         # scheduler -- the reference launches one process per sample -- gets from one GPU when the one-sample pass leaves it latency-bound.
@@ -551,19 +622,25 @@ def main():
         # 128 cores of the GPU boxes' hosts, and the baseline should be the CPU path at its best, not at its most oversubscribed
         cand = sorted({c for c in (8, 16, 32, 64, physical) if 1 <= c <= logical})
         calib = {}
+        chunk, variant = (5, "zt") if a.workload != "ddpm256" else (25, "xt")
         if "DPB_CPU_THREADS" in os.environ:
             cores = int(os.environ["DPB_CPU_THREADS"])
         else:
-            with torch.no_grad():
-                for c in cand:
-                    torch.set_num_threads(c)
-                    oracle_get_h(x_cpu)
-                    tq = time.perf_counter(); oracle_get_h(x_cpu); calib[c] = time.perf_counter() - tq
-                    if calib[c] > 1.5 * min(calib.values()):          # past the scaling knee: larger counts only oversubscribe
-                        break
+            # calibrated on what is timed -- ONE direction of JVP (jacfwd) + VJP (reverse mode) -- at every candidate count (no early stop:
+            # round 3's first-slow-sample rule picked 8 threads on one box and 32 on the next); a count is skipped only once the calibration
+            # itself has used up its budget
+            v1 = V0[:1].reshape(1, *shape)
+            t_cal = time.perf_counter()
+            for c in cand:
+                torch.set_num_threads(c)
+                tq = time.perf_counter()
+                u_c = opb.jvp_step(oracle_get_h, x_cpu, v1, 1, chunk, variant)
+                opb.vjp_step(oracle_get_h, x_cpu, u_c)
+                calib[c] = time.perf_counter() - tq
+                if time.perf_counter() - t_cal > 60.0:
+                    break
             cores = min(calib, key=calib.get)
         torch.set_num_threads(cores)
-        chunk, variant = (5, "zt") if a.workload != "ddpm256" else (25, "xt")
 
         def cpu_iteration(Vc):
             u_c = opb.jvp_step(oracle_get_h, x_cpu, Vc, Vc.shape[0], chunk, variant)
@@ -579,9 +656,10 @@ def main():
             Vc = cpu_iteration(Vc)
             times.append(time.perf_counter() - tc0)
         tc = sum(times) / len(times)
-        res["cpu_baseline"] = {"value": (ck / k) / tc, "unit": "iters/s", "cores": cores, "kind": "port", "cpu_model": model,
+        res["cpu_baseline"] = {"value": (ck / k) / tc, "unit": "iters/s", "cores": cores, "threads": cores, "kind": "port", "cpu_model": model,
                                "logical_cpus": logical, "physical_cores": physical,
-                               "thread_calibration_s_per_forward": {str(c): round(v, 3) for c, v in calib.items()},
+                               "cores_note": "`cores` = `threads` = torch intra-op THREADS used (the fastest of the calibration table), not a core reservation",
+                               "thread_calibration_s_per_jvp_vjp_direction": {str(c): round(v, 3) for c, v in calib.items()},
                                "sample": f"1 warm-up (1 direction, {tw:.1f}s) + {len(times)} timed power iterations (k={ck} of {k} directions; "
                                          f"JVP+VJP+SVD, fp32, {cores} threads) of the same workload: " + ", ".join(f"{x:.1f}s" for x in times)
                                          + ("" if ck == k else f", scaled by {ck}/{k}")}

@@ -1257,6 +1257,7 @@ static int attn_adj_route(int d, int L, int kps, int nt, bool have_drow) {
   return r;
 }
 // launches of launch_attn_adj_fused: query-major + key-major (+ the row-dot pre-pass when the key-major shared kernel cannot take D_t from the multi-cotangent one)
+int attn_adj_route_bits(int d, int L, int kps, int nt) { return attn_adj_route(d, L, kps, nt, true); }
 int attn_adj_launches(int d, int L, int kps, int nt) { const int r = attn_adj_route(d, L, kps, nt, true); return 2 + (r == 2); }
 
 int launch_attn_adj_fused(const FusedAttnArgs& f, int nt, hipStream_t st) {

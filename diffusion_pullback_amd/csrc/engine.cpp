@@ -141,7 +141,26 @@ int flush_pending(dpb_engine* e) {                 // the designated consumer di
   return launch_gemm_reduce(e->dtype, e->pend.a, e->stream);
 }
 
+// ---- measurement brackets (dpb_engine_profile): an event pair around one launch (or one fused group of launches) with its algorithmic flops.
+// kind: 0..6 the GEMM kernel kinds (include/dpb.h), 7 flash attention forward, 8 fused attention tangent, 9 fused attention adjoint (query-major +
+// key-major launches together; `gather` holds the route bits of attn_adj_route_bits), 10 one-launch cross-attention tangent / adjoint
+int prof_open(dpb_engine* e, double flops, int kind, int M, int N, int K, int Z, int gather) {
+  if (!e->profiling) return -1;
+  dpb_engine::Prof p;
+  p.flops = flops; p.big = kind; p.M = M; p.N = N; p.K = K; p.Z = Z; p.gather = gather;
+  if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+  (void)hipEventRecord(p.a, e->stream);
+  e->prof.push_back(p);
+  return (int)e->prof.size() - 1;
+}
+void prof_close(dpb_engine* e, int idx) {
+  if (idx >= 0) (void)hipEventRecord(e->prof[idx].b, e->stream);
+}
+
 int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false) {
+  // a product parked by an EARLIER gemm() of the same op (run_op has flushed everything older) must be reduced before this one reuses the slabs
+  if (e->pend.on)
+    if (int r = flush_pending(e)) return r;
   gemm_prep(e, a);
   GemmArgs* pend = (can_defer && g_lazy_reduce) ? &e->pend.a : nullptr;
   const double kk = (double)a.K + (a.A2 ? a.K2 : 0);
@@ -495,8 +514,12 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
     e->n_launch += 1;
     FusedAttnArgs f;
     fill_fused(e, p, x, f, 1, scale);
-    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * B * H;
-    return launch_attn_fwd_fused(f, B, x.O, (float*)(ws + p.stats), e->stream);
+    const double fl = 2.0 * p.Lq * (double)p.Lk * p.d * 2 * B * H;
+    e->flops += fl;
+    const int pi = prof_open(e, fl, 7, p.Lq, p.Lk, p.d, B * H, 0);
+    const int r = launch_attn_fwd_fused(f, B, x.O, (float*)(ws + p.stats), e->stream);
+    prof_close(e, pi);
+    return r;
   }
   GemmArgs g;   // S = scale * Q K^T
   g.A = x.Q; g.lda = x.ldq; g.sA1 = (long)p.Lq * x.ldq; g.sA2 = p.d;
@@ -549,8 +572,12 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
     FusedAttnArgs f;
     fill_fused(e, p, x, f, kps, scale);
     f.dQ = t.Q; f.dK = t.K; f.dV = t.V; f.dO = t.O;
-    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 5 * nt * H;
-    return launch_attn_jvp_fused(f, nt, e->stream);
+    const double fl = 2.0 * p.Lq * (double)p.Lk * p.d * 5 * nt * H;     // dS (2 products), dP V, P dV + the recomputed scores: 5 L x L x d products
+    e->flops += fl;
+    const int pi = prof_open(e, fl, 8, p.Lq, p.Lk, p.d, nt * H, 0);
+    const int r = launch_attn_jvp_fused(f, nt, e->stream);
+    prof_close(e, pi);
+    return r;
   }
   if (p.cross) {   // constant K/V: dO = [P o (scale dQ K^T - delta)] V in one launch
     CrossAttnArgs f;
@@ -558,8 +585,12 @@ int attn_tangent(dpb_engine* e, const Op& op, int nt) {
     f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = t.ldq; f.Cy = t.ldo;
     f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 0; f.scale = scale; f.fl = e->dtype == DT_F16;
     e->n_launch++;
-    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
-    return launch_attn_cross(f, nt, e->stream);
+    const double fl = 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
+    e->flops += fl;
+    const int pi = prof_open(e, fl, 10, p.Lq, p.Lk, p.d, nt * H, 0);
+    const int r = launch_attn_cross(f, nt, e->stream);
+    prof_close(e, pi);
+    return r;
   }
   GemmArgs g;   // dS = scale * dQ K^T
   g.A = t.Q; g.lda = t.ldq; g.sA1 = (long)p.Lq * t.ldq; g.sA2 = p.d;
@@ -608,8 +639,12 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
     fill_fused(e, p, x, f, kps, scale);
     f.gO = gO; f.gQ = (void*)c.Q; f.gK = (void*)c.K; f.gV = (void*)c.V; f.Drow = Dv;
     f.accQ = accQ; f.accK = accK; f.accV = accV;
-    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;
-    if (int r = launch_attn_adj_fused(f, nt, e->stream)) return r;
+    const double fl = 2.0 * p.Lq * (double)p.Lk * p.d * 7 * nt * H;     // query-major: scores, gP, gQ (3); key-major: scores^T, gP^T, gV, gK (4)
+    e->flops += fl;
+    const int pi = prof_open(e, fl, 9, p.Lq, p.Lk, p.d, nt * H, attn_adj_route_bits(p.d, p.Lq, kps, nt));
+    const int r = launch_attn_adj_fused(f, nt, e->stream);
+    prof_close(e, pi);
+    if (r) return r;
     e->ginit[d.in0] = e->ginit[d.in1] = e->ginit[d.in2] = 1;
     return 0;
   }
@@ -619,8 +654,12 @@ int attn_adjoint(dpb_engine* e, const Op& op, int nt) {
     f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = c.ldo; f.Cy = c.ldq;
     f.H = H; f.d = p.d; f.kps = kps; f.adjoint = 1; f.accumulate = accQ; f.scale = scale; f.fl = e->dtype == DT_F16;
     e->n_launch++;
-    e->flops += 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
-    if (int r = launch_attn_cross(f, nt, e->stream)) return r;
+    const double fl = 2.0 * p.Lq * (double)p.Lk * p.d * 2 * nt * H;
+    e->flops += fl;
+    const int pi = prof_open(e, fl, 10, p.Lq, p.Lk, p.d, nt * H, 1);
+    const int r = launch_attn_cross(f, nt, e->stream);
+    prof_close(e, pi);
+    if (r) return r;
     e->ginit[d.in0] = 1;
     return 0;
   }
@@ -990,6 +1029,7 @@ int dpb_read_buffer(dpb_engine* e, int buf, int channels, float* out) {
   const Buf& b = e->bufs[buf];
   if (channels < 1 || channels > b.C) return fail("bad channel count");
   int n = b.kind == DPB_BUF_SHARED ? 1 : e->cur_batch;
+  if (n < 1) return fail("no primal state to read (dpb_forward invalidates it; run dpb_primal first)");
   return launch_nhwc_to_nchw(e->dtype, e->P(buf), out, n, channels, b.rows, b.C, e->stream);
 }
 
@@ -1043,6 +1083,18 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
   OrthArgs a;
   a.W = W; a.Vprev = Vprev; a.V = V; a.s = s; a.conv = conv; a.scratch = (double*)scratch; a.k = k; a.N = N;
   a.scratch_bytes = orth_scratch_bytes(k, N);      // the caller's contract (include/dpb.h)
+  return launch_orth(a, (hipStream_t)stream);
+}
+
+int dpb_orth_checked(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, size_t scratch_bytes, int k, int64_t N,
+                     void* stream) {
+  if (!W || !Vprev || !V || !s || !conv || !scratch) return fail("null argument");
+  if (k < 1 || k > 56 || N < 1) return fail("dpb_orth: k=%d outside [1,56] or N=%lld < 1", k, (long long)N);
+  const size_t need = orth_scratch_bytes(k, N);
+  if (scratch_bytes < need) return fail("dpb_orth: scratch of %zu bytes, dpb_orth_scratch_bytes(%d, %lld) = %zu", scratch_bytes, k, (long long)N, need);
+  OrthArgs a;
+  a.W = W; a.Vprev = Vprev; a.V = V; a.s = s; a.conv = conv; a.scratch = (double*)scratch; a.k = k; a.N = N;
+  a.scratch_bytes = scratch_bytes;
   return launch_orth(a, (hipStream_t)stream);
 }
 

@@ -149,6 +149,7 @@ struct CrossAttnArgs {
 int cross_attention_supported(int dtype, int d, int Lq, int Lk, int kv_const);
 int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st);
 int launch_row_stats(int fl, const void* S, float* stats, long nrows, int Lk, int ld, hipStream_t st);
+int attn_adj_route_bits(int d, int L, int kps, int nt);   // bit 0: multi-cotangent query-major kernel, bit 1: shared-probability key-major kernel
 int attn_adj_launches(int d, int L, int kps, int nt);   // kernels launch_attn_adj_fused enqueues for such a layer (2 or 3)
 int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* stats, hipStream_t st);   // primal O + row statistics
 int launch_attn_jvp_fused(const FusedAttnArgs& f, int nt, hipStream_t st);

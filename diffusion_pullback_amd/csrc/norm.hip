@@ -516,6 +516,16 @@ __global__ void gn_finalize(double* st, int n_groups, double inv_n, double eps) 
   st[2 * i + 1] = 1.0 / sqrt(v + eps);
 }
 
+// pixels per block and statistics blocks per sample / tangent of the two-pass kernels: ONE rule for gn_launch and for groupnorm_launches
+// (the engine's launch count and its "is this a one-launch GroupNorm" test), so the two cannot drift
+static int gn_two_pass_ppb(int HW, int n) {
+  static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;   // tuning override
+  int ppb = 64;
+  while (ppb > 8 && (long)((HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
+  return ppb;
+}
+// gn_kernel's static LDS (lsum 2 KB + lseg 16 KB) + up to 48 KB dynamic = 66 KB: gfx950 (160 KB) only, like the rest of this library
+
 template <typename T, int MODE>
 static int gn_launch(const GNArgs& a, hipStream_t st) {
   constexpr int CH = TT<T>::CH;
@@ -530,9 +540,7 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
     return 0;
   }
   if (a.src.slab) { set_error("groupnorm: split-K slab input is taken by the one-launch kernel only"); return -1; }
-  int ppb = 64;
-  static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;   // tuning override
-  while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
+  const int ppb = gn_two_pass_ppb(a.HW, n);
   dim3 grid((a.HW + ppb - 1) / ppb, n);
   size_t lds = 0;
   if (a.det) {
@@ -561,9 +569,7 @@ int groupnorm_launches(int dtype, int mode, const GNArgs& a) {   // kernels laun
   if (gn_fused_groups(a.C, a.G, a.HW, dt_chunk(dtype), dtype == DT_F32 ? 4 : 2)) return 1;
   if (!a.det) return mode == MODE_PRIMAL ? 3 : 2;
   const int n = mode == MODE_PRIMAL ? a.Bp : a.NT;
-  int ppb = 64;
-  static const long gn_blocks = getenv("DPB_GN_BLOCKS") ? atol(getenv("DPB_GN_BLOCKS")) : 512;
-  while (ppb > 8 && (long)((a.HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
+  const int ppb = gn_two_pass_ppb(a.HW, n);
   return (a.HW + ppb - 1) / ppb <= GN_RED_MAX ? 2 : 3;
 }
 

@@ -61,6 +61,9 @@ template <int KMAX>
 __global__ __launch_bounds__(64) void eig_kernel(const double* Gp, int nbg, double* Cm, float* s_out, int k) {
   __shared__ double A[KMAX][KMAX + 1], Q[KMAX][KMAX + 1], X[KMAX * KMAX];
   __shared__ int order[KMAX];
+  // LDS budget: KMAX = 56 -> A + Q + X = 76 KB of static LDS: fine on gfx950 (160 KB per workgroup), over the 64 KB of gfx90a / gfx942.
+  // This library is gfx950-only by design (Makefile ARCH, no dual paths); the assert documents the ceiling instead of a launch failure elsewhere.
+  static_assert(sizeof(double) * (2 * KMAX * (KMAX + 1) + KMAX * KMAX) + sizeof(int) * KMAX <= 160 * 1024, "eig_kernel exceeds the gfx950 LDS");
   const int r = threadIdx.x;
   for (int e = r; e < k * k; e += 64) {          // Gram matrix and overlaps: the blocks' partials added in block order
     double g = 0.0, x = 0.0;

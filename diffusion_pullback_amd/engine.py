@@ -119,6 +119,8 @@ class Engine:
     def read(self, tap) -> torch.Tensor:
         buf = self.tape.taps[tap]
         c, h, w = self.tape.tap_shape[buf]
+        if self.batch < 1:
+            raise L.DpbError("no primal state to read: forward() keeps none (dpb_forward); call primal() first")
         with torch.cuda.device(self.device):
             self._set_stream()
             out = torch.empty(self.batch, c, h, w, dtype=torch.float32, device=self.device)
@@ -166,7 +168,7 @@ class Engine:
             s = torch.empty(k, dtype=torch.float32, device=self.device)
             conv = torch.empty(2, dtype=torch.float32, device=self.device)
             scratch = torch.empty(int(self.lib.dpb_orth_scratch_bytes(k, n)) // 8 + 1, dtype=torch.float64, device=self.device)
-            L.check(self.lib.dpb_orth(_ptr(W), _ptr(Vprev), _ptr(V), _ptr(s), _ptr(conv), _ptr(scratch), k, n, C.c_void_p(s_)))
+            L.check(self.lib.dpb_orth_checked(_ptr(W), _ptr(Vprev), _ptr(V), _ptr(s), _ptr(conv), _ptr(scratch), scratch.numel() * 8, k, n, C.c_void_p(s_)))
         return V, s, conv
 
     def iterate(self, tap, V: torch.Tensor, n_iters: int):

@@ -66,6 +66,7 @@ SYMBOLS = {
     "dpb_vjp": (_I, [_P, _I, _P, _I, _P]),
     "dpb_orth": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P]),
     "dpb_orth_scratch_bytes": (C.c_size_t, [_I, _L]),
+    "dpb_orth_checked": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _L, _P]),
     "dpb_pullback_iterate": (_I, [_P, _I, _P, _P, _P, _P, _I, _I]),
     "dpb_ddim_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
     "dpb_lincomb": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _P]),
@@ -107,26 +108,16 @@ def _built_hash() -> str:
 
 
 def _needs_build() -> bool:
-    """Stale or missing binary?  A prebuilt libdpb.so WITHOUT a stamp that is newer than every source is trusted (and stamped)."""
-    want = _source_hash()
-    if want == _built_hash():
-        return False
-    if os.path.exists(LIB_PATH) and not os.path.exists(STAMP_PATH):
-        srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp")) \
-            + [os.path.join(CSRC, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "dpb.h")]
-        if all(os.path.getmtime(f) <= os.path.getmtime(LIB_PATH) for f in srcs if os.path.exists(f)):
-            try:
-                with open(STAMP_PATH, "w") as fh:
-                    fh.write(want)
-            except OSError:
-                pass
-            return False
-    return True
+    """Stale or missing binary?  Only the content-hash stamp written by build() vouches for a libdpb.so: a binary without a stamp, or with another
+    hash, is rebuilt -- file times prove nothing after a checkout or copy that preserves them (a stale binary would otherwise be stamped as current
+    and edited kernels would run against it)."""
+    return _source_hash() != _built_hash()
 
 
 def build(force: bool = False) -> str:
     """Compile libdpb.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if force:
+    if force or (os.path.exists(LIB_PATH) and not os.path.exists(STAMP_PATH)):
+        # an unstamped binary says nothing about the objects next to it either: start from the sources
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
     r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
     if r.returncode != 0:

@@ -125,6 +125,12 @@ int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
              void* hip_stream);
 size_t dpb_orth_scratch_bytes(int k, int64_t N);   /* 0 for k outside [1, 56] */
+/* The same with the caller's scratch size stated and validated.  CONTRACT CHANGE of round 3, called out here because dpb_orth cannot check it: the
+ * scratch grew from 8 (3 k^2 + 2) bytes to dpb_orth_scratch_bytes(k, N) (per-block partials of the fixed-order reductions, up to ~129 k^2 + 512
+ * doubles); a caller that still sizes it by the old rule gets out-of-bounds device writes from dpb_orth.  New callers bind THIS entry point
+ * (the in-repo shim does): it fails with a message instead. */
+int dpb_orth_checked(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, size_t scratch_bytes, int k, int64_t N,
+                     void* hip_stream);
 
 /* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev, for all B samples
  * of the last dpb_primal together (independent bases, one shared weight stream; B*k <= max_tangents).
@@ -150,7 +156,10 @@ int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops,
  * events on the engine's stream; _read synchronises and sums the launches of one GEMM kernel kind: count, total
  * milliseconds, algorithmic flops.  kind: 0 register-staged 64x64, 1 register-staged 128x128, 2 BK=32 ring 128x128 /
  * 256x128, 3 BK=32 ring 64x64, 4 BK=64 ring with 128-column tiles (gemm_ring64.hip), 5 halo-tile 3x3 convolution (gemm_halo.hip), 6 BK=64 ring
- * with the 256x256 tile.  _dump writes one CSV line per recorded launch. */
+ * with the 256x256 tile; attention (algorithmic flops = 2 / 5 / 7 L x L x d products per head and sample / tangent / cotangent): 7 flash forward,
+ * 8 fused self-attention tangent, 9 fused self-attention adjoint (its query-major and key-major launches in ONE bracket; the CSV's `gather`
+ * column holds the route: bit 0 multi-cotangent query-major kernel, bit 1 shared-probability key-major kernel), 10 one-launch cross-attention
+ * tangent (gather 0) / adjoint (gather 1): 2 L x 77 x d products.  _dump writes one CSV line per recorded bracket. */
 int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);

@@ -19,19 +19,158 @@ transformer; time embedding [cos | sin] of dim 320, freq exponent -ln(1e4)*i/160
 the reference's unreachable utils.py:489-490 (its live branch :476-480 cannot run).
 
 Parameter names equal diffusers' ``state_dict`` keys so real weights can be fed
-when present.  Anchors: parameter count 859,520,964 (tests/test_oracle.py).
+when present.  Anchors: parameter counts 859,520,964 (SD-v1.5) and 865,910,724
+(SD-2.1-base) of this module's OWN shape table (tests/test_oracle.py).  The config
+dataclass and the shape table are the oracle's own (round 4): nothing but the seeded
+weight VALUES is shared with diffusion_pullback_amd/configs.py, and ``forward`` checks
+the shapes of the parameters it is handed against its own table.
 """
 from __future__ import annotations
 
 import math
+from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 
-from diffusion_pullback_amd.configs import SD15, Params, SDConfig  # noqa: F401  (shared config + synthetic weights)
-from diffusion_pullback_amd.configs import sd_init_params as init_params  # noqa: F401
-from diffusion_pullback_amd.configs import sd_param_shapes as param_shapes  # noqa: F401
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass(frozen=True)
+class SDConfig:
+    """The oracle's OWN reading of diffusers' ``unet/config.json`` -- deliberately not imported from the product
+    package: a wrong head count, width or projection kind in ``diffusion_pullback_amd/configs.py`` must not be shared by the checker.
+    Field names follow the product's dataclass so that fixtures (``SDConfig(**f["cfg"])``) and duck-typed callers work with either."""
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    down_attn: Tuple[bool, ...] = (True, True, True, False)      # CrossAttnDownBlock2D x3, DownBlock2D
+    up_attn: Tuple[bool, ...] = (False, True, True, True)        # UpBlock2D, CrossAttnUpBlock2D x3
+    heads: Tuple[int, ...] = (8, 8, 8, 8)                        # ``attention_head_dim`` of diffusers 0.11 = head COUNT per down block
+    cross_dim: int = 768
+    groups: int = 32
+    sample_size: int = 64
+    use_linear_projection: bool = False
+    ctx_len: int = 77
+
+    @property
+    def temb_ch(self) -> int:
+        return 4 * self.block_out_channels[0]
+
+
+# runwayml/stable-diffusion-v1-5 unet/config.json (BASELINE.json configs[2..4])
+SD15 = SDConfig()
+# stabilityai/stable-diffusion-2-1-base unet/config.json -- the model id of the reference's SD scripts
+# (src/scripts/main_various_local_encoder_pullback_with_edit_prompt.sh:11): attention_head_dim [5, 10, 20, 20] (64-wide heads),
+# cross_attention_dim 1024 (OpenCLIP-H), use_linear_projection true
+SD21_BASE = SDConfig(heads=(5, 10, 20, 20), cross_dim=1024, use_linear_projection=True)
+
+
+def param_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """``state_dict`` keys and shapes of diffusers' UNet2DConditionModel for ``cfg`` -- the oracle's own table, written from the module
+    tree of the published class (anchors: 859,520,964 parameters for SD-v1.5, 865,910,724 for SD-2.1-base; tests/test_oracle.py)."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    C = tuple(cfg.block_out_channels)
+    T = 4 * C[0]
+
+    def affine(name, n):                               # GroupNorm / LayerNorm
+        out[f"{name}.weight"] = (n,)
+        out[f"{name}.bias"] = (n,)
+
+    def conv2d(name, cin, cout, ks):
+        out[f"{name}.weight"] = (cout, cin, ks, ks)
+        out[f"{name}.bias"] = (cout,)
+
+    def linear(name, cin, cout, bias=True):
+        out[f"{name}.weight"] = (cout, cin)
+        if bias:
+            out[f"{name}.bias"] = (cout,)
+
+    def ResnetBlock2D(name, cin, cout):
+        affine(f"{name}.norm1", cin)
+        conv2d(f"{name}.conv1", cin, cout, 3)
+        linear(f"{name}.time_emb_proj", T, cout)
+        affine(f"{name}.norm2", cout)
+        conv2d(f"{name}.conv2", cout, cout, 3)
+        if cin != cout:
+            conv2d(f"{name}.conv_shortcut", cin, cout, 1)
+
+    def CrossAttention(name, width, kv_width):
+        linear(f"{name}.to_q", width, width, bias=False)
+        linear(f"{name}.to_k", kv_width, width, bias=False)
+        linear(f"{name}.to_v", kv_width, width, bias=False)
+        linear(f"{name}.to_out.0", width, width)
+
+    def Transformer2DModel(name, width):
+        affine(f"{name}.norm", width)
+        for proj in ("proj_in", "proj_out"):
+            if cfg.use_linear_projection:
+                linear(f"{name}.{proj}", width, width)
+            else:
+                conv2d(f"{name}.{proj}", width, width, 1)
+        blk = f"{name}.transformer_blocks.0"           # BasicTransformerBlock, depth 1
+        affine(f"{blk}.norm1", width)
+        CrossAttention(f"{blk}.attn1", width, width)
+        affine(f"{blk}.norm2", width)
+        CrossAttention(f"{blk}.attn2", width, cfg.cross_dim)
+        affine(f"{blk}.norm3", width)
+        linear(f"{blk}.ff.net.0.proj", width, 2 * 4 * width)      # GEGLU: value | gate
+        linear(f"{blk}.ff.net.2", 4 * width, width)
+
+    linear("time_embedding.linear_1", C[0], T)
+    linear("time_embedding.linear_2", T, T)
+    conv2d("conv_in", cfg.in_channels, C[0], 3)
+    skip_widths = [C[0]]                               # what the up path will pop, in push order
+    width = C[0]
+    for i, cout in enumerate(C):
+        for j in range(cfg.layers_per_block):
+            ResnetBlock2D(f"down_blocks.{i}.resnets.{j}", width, cout)
+            width = cout
+            if cfg.down_attn[i]:
+                Transformer2DModel(f"down_blocks.{i}.attentions.{j}", width)
+            skip_widths.append(width)
+        if i + 1 < len(C):
+            conv2d(f"down_blocks.{i}.downsamplers.0.conv", width, width, 3)
+            skip_widths.append(width)
+    ResnetBlock2D("mid_block.resnets.0", width, width)
+    Transformer2DModel("mid_block.attentions.0", width)
+    ResnetBlock2D("mid_block.resnets.1", width, width)
+    for i, cout in enumerate(reversed(C)):
+        for j in range(cfg.layers_per_block + 1):
+            ResnetBlock2D(f"up_blocks.{i}.resnets.{j}", width + skip_widths.pop(), cout)
+            width = cout
+            if cfg.up_attn[i]:
+                Transformer2DModel(f"up_blocks.{i}.attentions.{j}", width)
+        if i + 1 < len(C):
+            conv2d(f"up_blocks.{i}.upsamplers.0.conv", width, width, 3)
+    assert not skip_widths
+    affine("conv_norm_out", C[0])
+    conv2d("conv_out", C[0], cfg.out_channels, 3)
+    return out
+
+
+def check_params(p: Params, cfg) -> None:
+    """Every tensor of ``p`` has the key and shape the oracle's own table gives for ``cfg`` (``p`` may be a prefix-restricted subset)."""
+    want = param_shapes(cfg)
+    for k, v in p.items():
+        if k not in want:
+            raise KeyError(f"parameter {k!r} is not a key of UNet2DConditionModel for {cfg}")
+        if tuple(v.shape) != want[k]:
+            raise ValueError(f"parameter {k!r} has shape {tuple(v.shape)}, the oracle's table for {cfg} says {want[k]}")
+
+
+def init_params(cfg, seed: int = 0, gain: float = 1.0, dtype=torch.float32, only_prefix=None, spectrum=None) -> Params:
+    """Seeded synthetic weights.  Only the VALUES are shared with the product (one generator stream, so the HIP engine and this oracle see the
+    same bits: diffusion_pullback_amd.configs.sd_init_params); the names and shapes they arrive under are checked against this module's own
+    table, and a full draw must cover it exactly."""
+    from diffusion_pullback_amd.configs import sd_init_params
+    p = sd_init_params(cfg, seed=seed, gain=gain, dtype=dtype, only_prefix=only_prefix, spectrum=spectrum)
+    check_params(p, cfg)
+    if only_prefix is None and set(p) != set(param_shapes(cfg)):
+        raise KeyError(f"synthetic weights miss {sorted(set(param_shapes(cfg)) - set(p))[:5]} ...")
+    return p
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -97,8 +236,9 @@ def _transformer(p, pre, x, ctx, heads, cfg):
     return h + x
 
 
-def forward(p: Params, cfg: SDConfig, x, t, ctx, stop: Optional[Tuple[str, int]] = None):
+def forward(p: Params, cfg, x, t, ctx, stop: Optional[Tuple[str, int]] = None):
     """``stop=(op, idx)`` -> feature map of get_h (utils.py:438-527); None -> eps."""
+    check_params(p, cfg)
     if not torch.is_tensor(t):
         t = torch.tensor([float(t)])
     t = t.reshape(-1) if t.dim() else t[None]

@@ -2,13 +2,16 @@
 
 Run in the build container only (needs /root/reference; ~30-40 min on 8 vCPU):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_fullsize.py [sd15] [ddpm256]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_fullsize.py [sd15] [ddpm256] [sd21]
 
   pullback_sd15_mid_k5.pt    utils.local_encoder_pullback_zt (reference src/utils/utils.py:722-816) bound with
                              types.MethodType onto an object whose get_h is the full-size SD-v1.5 oracle net
                              (oracle.unet_sd, shaped-spectrum weights configs.sd_init_params(SD15, seed 0, Spectrum())):
                              z_t[1,4,64,64], ctx[1,77,768], t = 696.2727, op 'mid', pca_rank 5, chunk_size 5, the
                              reference's default stop rule (min_iter 10, atol 1e-3) capped at max_iter 12  (BASELINE configs[2])
+  pullback_sd21_mid_k2.pt    the same function on the full-size SD-2.1-base oracle net (the reference scripts' default model id; ctx[1,77,1024],
+                             64-wide heads, Linear proj_in / proj_out), pca_rank 2, 12 iterations -- the settings of the reference's only
+                             published timing (example-code.ipynb:123-145)
   pullback_ddpm256_mid_k5.pt the vendored PullBackDDPM.local_encoder_pullback_xt (src/models/ddpm/diffusion.py:484-556)
                              of the full-size CelebA-HQ-256 net (config src/configs/custom_celeba_ddpm.yml) with
                              configs.ddpm_init_params(CELEBA_HQ_256, seed 0, Spectrum()): x[1,3,256,256], t = 600, k = 5,
@@ -66,7 +69,7 @@ def sd15(ru):
         dtype = torch.float32
 
         def get_h(self, sample=None, timestep=None, encoder_hidden_states=None, op=None, block_idx=None, verbose=False):
-            return unet_sd.forward(params, cf.SD15, sample, timestep, encoder_hidden_states, stop=(op, block_idx))
+            return unet_sd.forward(params, unet_sd.SD15, sample, timestep, encoder_hidden_states, stop=(op, block_idx))   # the oracle's own config
 
     net = Net()
     net.local_encoder_pullback_zt = types.MethodType(ru.local_encoder_pullback_zt, net)
@@ -80,6 +83,38 @@ def sd15(ru):
            "s": s.clone(), "vT": vT.clone(), "u_norms": u.norm(dim=0).clone(), "u_head": u[:256].clone(), "seconds": dt}
     torch.save(fix, os.path.join(HERE, "pullback_sd15_mid_k5.pt"))
     print("sd15: %d iterations in %.0f s; s = %s; dist = %s" % (len(hist), dt, s.tolist(), hist), flush=True)
+
+
+def sd21(ru):
+    """The reference scripts' own default model (stabilityai/stable-diffusion-2-1-base, src/scripts/main_various_local_encoder_pullback_with_edit_prompt.sh:11)
+    at the settings of its only published timing (example-code.ipynb:123-145: pca_rank 2, fp32, 12 iterations)."""
+    from diffusion_pullback_amd import configs as cf
+    from oracle import unet_sd
+    enc = ("time_embedding", "conv_in", "down_blocks", "mid_block")
+    params = cf.sd_init_params(cf.SD21_BASE, seed=0, only_prefix=enc, spectrum=cf.Spectrum())
+    g = torch.Generator().manual_seed(0)                       # == tests/test_gpu_fullsize.py::_sd21_inputs
+    ctx = torch.randn(1, 77, 1024, generator=g)
+    z = torch.randn(1, 4, 64, 64, generator=g)
+
+    class Net:
+        dtype = torch.float32
+
+        def get_h(self, sample=None, timestep=None, encoder_hidden_states=None, op=None, block_idx=None, verbose=False):
+            return unet_sd.forward(params, unet_sd.SD21_BASE, sample, timestep, encoder_hidden_states, stop=(op, block_idx))   # the oracle's own config
+
+    net = Net()
+    net.local_encoder_pullback_zt = types.MethodType(ru.local_encoder_pullback_zt, net)
+    k = 2
+    torch.manual_seed(RNG_SEED)
+    (u, s, vT), log, dt = _run(lambda: net.local_encoder_pullback_zt(z, torch.tensor(T_SD), ctx, op="mid", block_idx=0, pca_rank=k, chunk_size=5,
+                                                                     min_iter=10, max_iter=MAX_ITER, convergence_threshold=1e-3))
+    hist = _history(log)
+    fix = {"workload": "sd21-base mid k2", "weights": "configs.sd_init_params(SD21_BASE, seed=0, only_prefix=ENC, spectrum=Spectrum())",
+           "inputs": "Generator(0): ctx = randn(1,77,1024); z = randn(1,4,64,64)", "t": T_SD, "rng_seed": RNG_SEED, "k": k, "chunk_size": 5,
+           "min_iter": 10, "max_iter": MAX_ITER, "thr": 1e-3, "iters": len(hist), "dist_history": hist,
+           "s": s.clone(), "vT": vT.clone(), "u_norms": u.norm(dim=0).clone(), "u_head": u[:256].clone(), "seconds": dt}
+    torch.save(fix, os.path.join(HERE, "pullback_sd21_mid_k2.pt"))
+    print("sd21: %d iterations in %.0f s; s = %s; dist = %s" % (len(hist), dt, s.tolist(), hist), flush=True)
 
 
 def ddpm256(ru, rd):
@@ -115,6 +150,8 @@ def main():
         ddpm256(ru, rd)
     if "sd15" in which:
         sd15(ru)
+    if "sd21" in which:
+        sd21(ru)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

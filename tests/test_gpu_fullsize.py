@@ -50,10 +50,36 @@ def _sd15(dtype, k=5, max_batch=1, full=False):
 
 
 def _oracle_f(full, tap, ctx):
-    from diffusion_pullback_amd import configs as cf
     from oracle import unet_sd
-    p = _sd15_params(full)
-    return lambda a: unet_sd.forward(p, cf.SD15, a, torch.tensor(T_SD), ctx.expand(a.shape[0], -1, -1), stop=tap)
+    p = _sd15_params(full)                      # seeded VALUES only; the oracle walks them with its OWN config and shape table
+    return lambda a: unet_sd.forward(p, unet_sd.SD15, a, torch.tensor(T_SD), ctx.expand(a.shape[0], -1, -1), stop=tap)
+
+
+# ---- SD-2.1-base: the model id of the reference's own SD scripts (src/scripts/main_various_local_encoder_pullback_with_edit_prompt.sh:11)
+@functools.lru_cache(maxsize=None)
+def _sd21_params(full: bool):
+    from diffusion_pullback_amd import configs as cf
+    return cf.sd_init_params(cf.SD21_BASE, seed=0, only_prefix=None if full else ENC, spectrum=cf.Spectrum())
+
+
+@functools.lru_cache(maxsize=None)
+def _sd21_inputs():
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randn(1, 77, 1024, generator=g)
+    z = torch.randn(1, 4, 64, 64, generator=g)
+    return z, ctx
+
+
+def _sd21(dtype, k=2, full=False):
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    return PullbackUNet("sd", cf.sd_config_for("stabilityai/stable-diffusion-2-1-base"), _sd21_params(full), dtype=dtype, device=DEV, max_batch=1,
+                        max_rank=k, upto=("up", 3) if full else ("mid", 0), verbose=False)
+
+
+def _oracle_f21(full, tap, ctx):
+    from oracle import unet_sd
+    p = _sd21_params(full)
+    return lambda a: unet_sd.forward(p, unet_sd.SD21_BASE, a, torch.tensor(T_SD), ctx.expand(a.shape[0], -1, -1), stop=tap)
 
 
 @pytest.fixture(scope="module")
@@ -71,6 +97,23 @@ def oracle_taps():
     out = {}
     for tap in TAPS:
         f = _oracle_f(True, tap, ctx)
+        with torch.no_grad():
+            h = f(z)
+        U = torch.randn(1, h.numel(), generator=g)
+        out[tap] = dict(h=h, V=V, JV=oracle_jvp(f, z, V), U=U, JTU=oracle_vjp(f, z, U))
+    return out
+
+
+@pytest.fixture(scope="module")
+def oracle_taps_sd21():
+    """One direction of primal / JVP / VJP of the full SD-2.1-base U-Net at every tap, fp32 CPU oracle with the oracle's own SD21_BASE."""
+    _threads()
+    z, ctx = _sd21_inputs()
+    g = torch.Generator().manual_seed(3)
+    V = torch.randn(1, 16384, generator=g)
+    out = {}
+    for tap in TAPS:
+        f = _oracle_f21(True, tap, ctx)
         with torch.no_grad():
             h = f(z)
         U = torch.randn(1, h.numel(), generator=g)
@@ -137,6 +180,25 @@ def test_sd15_every_tap_one_direction_vs_oracle(dtype, oracle_taps):
     assert not bad, f"(primal, jvp, vjp) relative errors over {tol}: {bad}"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_sd21_base_every_tap_one_direction_vs_oracle(dtype, oracle_taps_sd21):
+    """The reference scripts' default model (stabilityai/stable-diffusion-2-1-base) at FULL size: primal, JVP and VJP of one direction at every
+    tap against the fp32 CPU oracle walking the same seeded values with its own SD21_BASE (1024-wide context, 5 / 10 / 20 / 20 heads of 64,
+    Linear proj_in / proj_out).  Runs the d = 64 fused attention kernels at L = 4096 / 1024 / 256 / 64 and the 1024-wide text K / V products."""
+    z, ctx = _sd21_inputs()
+    net = _sd21(dtype, k=1, full=True)
+    e = net.engine
+    tol = TOL[dtype]
+    errs = {}
+    for tap in TAPS:
+        o = oracle_taps_sd21[tap]
+        e.primal(z, T_SD, ctx, tap)
+        errs[tap] = (rel(e.read(tap), o["h"]), rel(e.jvp(tap, o["V"].to(DEV)), o["JV"]), rel(e.vjp(tap, o["U"].to(DEV)), o["JTU"]))
+    print("sd21", dtype, {k: tuple(round(x, 5) for x in v) for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not all(x < tol for x in v)}
+    assert not bad, f"(primal, jvp, vjp) relative errors over {tol}: {bad}"
+
+
 # ------------------------------------------------------------------------------------------------ the algorithm vs the oracle
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
 def test_sd15_pullback_two_iterations_vs_oracle(dtype, oracle_pullback_k5):
@@ -192,16 +254,17 @@ def test_sd15_converges_under_reference_stop_rule(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[3]
-def test_sd15_config3_k10_samples_advanced_together():
+@pytest.mark.parametrize("S", [4, 8], ids=["S4", "S8"])
+def test_sd15_config3_k10_samples_advanced_together(S):
     """configs[3]: edit-prompt context, k = 10, several x_t samples advanced together on one GPU (one rank's share of the 64-sample
     job), the bench's own 12 iterations: the batched run equals one-at-a-time runs in ALL ten vectors (|cos| >= 0.99, s to 2 %), and one of
-    the ten tangents / cotangents equals the oracle JVP / VJP of that direction."""
+    the ten tangents / cotangents of the LAST sample's block of the batched pass equals the oracle JVP / VJP of that direction.  S = 8 is the
+    batch bench.py's strong leg runs (nt = 80: the launches that go to the 256 x 256 tile); S = 4 is the shape that overflowed the split-K slabs in round 2."""
     _threads()
-    _, ctx0 = _sd15_inputs()
-    k, S, iters = 10, 4, 12
+    k, iters = 10, 12
     g = torch.Generator().manual_seed(77)
     ctx = torch.randn(1, 77, 768, generator=g)                                   # seeded "edit prompt" embedding (not the null ctx)
-    zs = torch.randn(S, 4, 64, 64, generator=g)
+    zs = torch.cat([torch.randn(4, 4, 64, 64, generator=g), torch.randn(4, 4, 64, 64, generator=torch.Generator().manual_seed(78))])[:S]
     V0 = torch.linalg.qr(torch.randn(16384, k, generator=g))[0].T.contiguous()
     net = _sd15(torch.bfloat16, k=k, max_batch=S)
     _, s_b, V_b, _ = net.pullback_fixed(zs, T_SD, ctx.expand(S, -1, -1), "mid", 0, k, iters, V0)
@@ -217,14 +280,16 @@ def test_sd15_config3_k10_samples_advanced_together():
         assert (cos > 0.99).all(), (i, cos)
     # distinct samples have distinct bases (the batch is not one sample repeated)
     assert abs_cos(V_b[0:1], V_b[k:k + 1]).item() < 0.99
+    # one oracle direction out of the LAST sample's block of the BATCHED tangent / adjoint pass (nt = S * k rows in every launch)
     e = net.engine
-    e.primal(zs[0:1], T_SD, ctx, ("mid", 0))
-    U = e.jvp(("mid", 0), V0.to(DEV))                                             # nt = 10 tangents in one pass
+    last = S - 1
+    e.primal(zs, T_SD, ctx.expand(S, -1, -1), ("mid", 0))
+    U = e.jvp(("mid", 0), V0.repeat(S, 1).to(DEV))
     f = _oracle_f(False, ("mid", 0), ctx)
-    assert rel(U[7:8], oracle_jvp(f, zs[0:1], V0[7:8])) < TOL[torch.bfloat16]
+    assert rel(U[last * k + 7:last * k + 8], oracle_jvp(f, zs[last:last + 1], V0[7:8])) < TOL[torch.bfloat16]
     Uc = torch.randn(k, 81920, generator=g)
-    W = e.vjp(("mid", 0), Uc.to(DEV))                                             # nt = 10 cotangents in one pass
-    assert rel(W[3:4], oracle_vjp(f, zs[0:1], Uc[3:4])) < TOL[torch.bfloat16]
+    W = e.vjp(("mid", 0), Uc.repeat(S, 1).to(DEV))
+    assert rel(W[last * k + 3:last * k + 4], oracle_vjp(f, zs[last:last + 1], Uc[3:4])) < TOL[torch.bfloat16]
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[1]
@@ -290,6 +355,25 @@ def test_sd15_headline_vs_reference_function_golden(dtype):
     uh, rh = u[:256].float().cpu(), fix["u_head"]
     sign = torch.sign((uh * rh).sum(0, keepdim=True))
     assert rel(uh * sign, rh) < (2e-3 if dtype == torch.float32 else 1e-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_sd21_base_k2_vs_reference_function_golden(dtype):
+    """The reference scripts' default model at the settings of its only published timing (example-code.ipynb:123-145: pca_rank 2, 12 iterations):
+    (s, vT) RETURNED BY THE REFERENCE'S OWN utils.local_encoder_pullback_zt bound onto the full-size SD-2.1-base oracle net
+    (tests/golden/make_golden_fullsize.py sd21).  The product draws the same V0 under the recorded seed."""
+    from _util import load_golden
+    fix = load_golden("pullback_sd21_mid_k2.pt")
+    assert fix["iters"] == 12 and fix["k"] == 2
+    z, ctx = _sd21_inputs()
+    net = _sd21(dtype)
+    torch.manual_seed(fix["rng_seed"])
+    u, s, vT = net.local_encoder_pullback_zt(z, torch.tensor(T_SD), ctx, op="mid", block_idx=0, pca_rank=2, chunk_size=fix["chunk_size"],
+                                             min_iter=fix["min_iter"], max_iter=fix["max_iter"], convergence_threshold=fix["thr"])
+    assert net.last_iters == 12
+    _check_vs_reference(fix, s, vT, dtype)
+    un = u.float().cpu().norm(dim=0)
+    assert torch.allclose(un, fix["u_norms"], rtol=1e-3 if dtype == torch.float32 else 3e-2), (un, fix["u_norms"])
 
 
 def test_ddpm256_headline_vs_reference_function_golden():

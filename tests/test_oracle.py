@@ -65,6 +65,32 @@ def test_sd15_param_count():
     assert abs(enc - 348.7e6) < 0.1e6
 
 
+def test_sd21_base_param_count_and_independent_tables():
+    """The oracle's shape table and config constants are its OWN (oracle/unet_sd.py does not import the product's): the published sizes of both
+    SD U-Nets anchor it, and the product's table (diffusion_pullback_amd/configs.py) must agree with it key by key -- two readings of the
+    published architecture, cross-checked, instead of one reading shared through an import."""
+    import dataclasses
+    import inspect
+    from diffusion_pullback_amd import configs as cf
+    src = inspect.getsource(unet_sd)
+    assert "from diffusion_pullback_amd.configs import SD" not in src and "sd_param_shapes" not in src
+    shapes21 = unet_sd.param_shapes(unet_sd.SD21_BASE)
+    assert sum(torch.Size(s).numel() for s in shapes21.values()) == 865_910_724      # published SD-2.x U-Net size
+    assert shapes21["mid_block.attentions.0.proj_in.weight"] == (1280, 1280)         # Linear, not 1x1 conv
+    assert shapes21["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 1024)
+    for own, prod in ((unet_sd.SD15, cf.SD15), (unet_sd.SD21_BASE, cf.SD21_BASE)):
+        assert dataclasses.asdict(own) == dataclasses.asdict(prod)
+        assert unet_sd.param_shapes(own) == cf.sd_param_shapes(prod)
+    assert cf.sd_config_for("stabilityai/stable-diffusion-2-1-base") is cf.SD21_BASE
+    # a product-side misreading is caught: a parameter set drawn for the wrong head layout / context width does not pass the oracle's check
+    wrong = cf.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(2, 2),
+                        cross_dim=24, groups=8, sample_size=8, ctx_len=5)
+    right = unet_sd.SDConfig(block_out_channels=(32, 64), layers_per_block=1, down_attn=(True, False), up_attn=(False, True), heads=(2, 2),
+                             cross_dim=16, groups=8, sample_size=8, ctx_len=5)
+    with pytest.raises(ValueError):
+        unet_sd.check_params(cf.sd_init_params(wrong, seed=0), right)
+
+
 def test_pullback_xt_matches_vendored_reference():
     f = _load("pullback_xt_ddpm.pt")
     cfg = unet_ddpm.DDPMConfig(**f["cfg"])

@@ -49,10 +49,21 @@ def main():
             continue
         b = (2.0 * v["fetch_kb_per_launch"] + v["write_kb_per_launch"]) * 1024.0 * v["launches"] / pmc_iters
         hbm[family(k)] = hbm.get(family(k), 0.0) + b
-    flops = {}
+    flops, gemm_fams = {}, set()
     for r in csv.DictReader(open(os.path.join(DIR, n_csv))):
-        f = KIND.get(r["big"], "gemm_kernel")
-        flops[f] = flops.get(f, 0.0) + 2.0 * float(r["M"]) * float(r["N"]) * float(r["K"]) * float(r["Z"])
+        big, mnkz = int(r["big"]), 2.0 * float(r["M"]) * float(r["N"]) * float(r["K"]) * float(r["Z"])
+        if big <= 6:
+            f = KIND.get(r["big"], "gemm_kernel")
+            flops[f] = flops.get(f, 0.0) + mnkz
+            gemm_fams.add(f)
+            continue
+        # attention brackets (round 4): M = L, N = Lk, K = d, Z = heads x (samples | tangents | cotangents); algorithmic L x L x d products:
+        # forward 2, tangent 5, adjoint 7 = 3 in the query-major kernel (scores, gP, gQ) + 4 in the key-major one (scores^T, gP^T, gV, gK), cross 2
+        route = int(r["gather"])
+        for f, n in {7: [("attn_fwd_kernel", 2)], 8: [("attn_jvp_kernel", 5)], 10: [("attn_cross_kernel", 2)],
+                     9: [("attn_adj_q_multi_kernel" if route & 1 else "attn_adj_q_kernel", 3),
+                         ("attn_adj_kv_shared_kernel" if route & 2 else "attn_adj_kv_kernel", 4)]}.get(big, []):
+            flops[f] = flops.get(f, 0.0) + n * mnkz
     mfma = {}                                                       # family -> (MFMA busy cycles, SIMD-cycles available) from the SQ pass, if collected
     pm = os.path.join(DIR, n_pmc)
     if os.path.exists(pm):
@@ -79,12 +90,23 @@ def main():
         print(f"| `{f}` | {ms:.3f} | {100 * ms / total:.1f} % | {calls / ITERS:.1f} | " + (f"{tf:.0f} | {100 * tf / PEAK_TF:.1f} % | " if tf else "– | – | ") +
               (f"{100 * mfma[f][0] / mfma[f][1]:.1f} % | " if f in mfma and mfma[f][1] > 0 and mfma[f][0] > 0 else "– | ") +
               (f"{gb / 1e9:.2f} | {tbs:.2f} | {100 * tbs / PEAK_HBM:.0f} % |" if gb else "– | – | – |"))
-    gemm_ms = sum(fam[f][0] for f in flops if f in fam)
+    gemm_ms = sum(fam[f][0] for f in gemm_fams if f in fam)
+    gemm_fl = sum(flops[f] for f in gemm_fams)
+    att_fams = [f for f in flops if f not in gemm_fams and f in fam]
+    att_ms, att_fl = sum(fam[f][0] for f in att_fams), sum(flops[f] for f in att_fams)
+    hbm_total = sum(hbm.values())
     print("\n'MFMA pipe busy' = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) from the separate SQ counter pass (issued MFMAs incl. padded "
           "tile lanes; counter passes run ~1.4x slower than un-profiled ones, so it under-reads the un-profiled utilisation).")
-    print(f"\nAll GEMM / convolution kernels together: {sum(flops.values()) / 1e12:.2f} TFLOP in {gemm_ms:.2f} ms = "
-          f"{sum(flops.values()) / (gemm_ms * 1e-3) / 1e12:.0f} TFLOP/s ({100 * sum(flops.values()) / (gemm_ms * 1e-3) / 1e12 / PEAK_TF:.1f} % of the MFMA peak); "
-          f"the attention kernels' flops are not in the per-launch CSV (5 / 7 L×L×d products per tangent / cotangent and head).")
+    print(f"\nAll GEMM / convolution kernels together: {gemm_fl / 1e12:.2f} TFLOP in {gemm_ms:.2f} ms = "
+          f"{gemm_fl / (gemm_ms * 1e-3) / 1e12:.0f} TFLOP/s ({100 * gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_TF:.1f} % of the MFMA peak).")
+    if att_ms > 0:
+        print(f"\nAttention kernels together (algorithmic L×L×d products per head: forward 2, tangent 5, adjoint 7 = 3 query-major + 4 key-major, "
+              f"cross-attention 2): {att_fl / 1e12:.2f} TFLOP in {att_ms:.2f} ms = {att_fl / (att_ms * 1e-3) / 1e12:.0f} TFLOP/s "
+              f"({100 * att_fl / (att_ms * 1e-3) / 1e12 / PEAK_TF:.1f} % of the MFMA peak); the shared-probability kernels issue fewer MFMAs than the algorithmic count.")
+    if hbm_total > 0:
+        print(f"\nWhole iteration: {hbm_total / 1e9:.2f} GB of HBM traffic in {total:.2f} ms of kernel time = {hbm_total / (total * 1e-3) / 1e12:.2f} TB/s "
+              f"({100 * hbm_total / (total * 1e-3) / 1e12 / PEAK_HBM:.0f} % of the HBM peak); {(gemm_fl + att_fl) / 1e12:.2f} TFLOP (products + attention) = "
+              f"{(gemm_fl + att_fl) / (total * 1e-3) / 1e12:.0f} TFLOP/s ({100 * (gemm_fl + att_fl) / (total * 1e-3) / 1e12 / PEAK_TF:.1f} % of the MFMA peak).")
 
 
 if __name__ == "__main__":
