@@ -124,9 +124,76 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& p, bf16* C, const bf
   }
 }
 
+// ---- GroupNorm statistics of the output, from the epilogue (GnStat, kernels.h).  A lane keeps its 16-byte column across the items and slabs of its
+// wave's row strip, so it sums its rows in registers (GsAcc), the RPI lanes of a column are folded by a fixed xor tree, and ONE lane per column stores
+// the strip's float4 partial: no atomics, no LDS, the same additions in the same order every run.
+struct GsAcc { float s[4] = {0.f, 0.f, 0.f, 0.f}; };
+template <int FL>
+struct GsCtx {                       // per-lane constants of the statistics (filled once per wave strip: gs_begin)
+  int split = 8;                     // elements e >= split of the chunk belong to the chunk's second group
+  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+  float gam[8], bet[8];
+  const bf16* xrow = nullptr;        // primal rows of this strip's sample: x + (sample * HW) * N + n
+};
+template <int FL>
+__device__ __forceinline__ void gs_begin(const GemmArgs& p, int mstrip0, int n, GsCtx<FL>& c) {
+  const GnStat& g = p.gs;
+  const int g0 = n / g.cpg;
+  c.split = (g0 + 1) * g.cpg - n;
+  if (g.mode >= 2) {
+    const int mm = min(mstrip0, p.M - 1);
+    const int smp = (mm / g.HW) / g.kps;                       // the whole strip lies in one tangent / cotangent (HW % strip rows == 0)
+    const int g1 = min(g0 + 1, g.G - 1);
+    c.mean[0] = (float)g.pstats[((long)smp * g.G + g0) * 2]; c.rstd[0] = (float)g.pstats[((long)smp * g.G + g0) * 2 + 1];
+    c.mean[1] = (float)g.pstats[((long)smp * g.G + g1) * 2]; c.rstd[1] = (float)g.pstats[((long)smp * g.G + g1) * 2 + 1];
+    c.xrow = (const bf16*)g.x + (long)smp * g.HW * p.N + n;
+    if (g.mode == 3) {
+      Vec<float>::load(g.gamma + n, c.gam); Vec<float>::load(g.gamma + n + 4, c.gam + 4);
+      Vec<float>::load(g.beta + n, c.bet); Vec<float>::load(g.beta + n + 4, c.bet + 4);
+    }
+  }
+}
+// o: the 8 output values of one row as STORED (rounded to 16 bit); xr: the primal row chunk (modes 2, 3)
+template <int FL>
+__device__ __forceinline__ void gs_add(const GnStat& g, const GsCtx<FL>& c, const float* o, const uint4& xr, GsAcc& a) {
+  float x[8];
+  if (g.mode >= 2) H16<FL>::load8(reinterpret_cast<const bf16*>(&xr), x);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int hi = e >= c.split ? 1 : 0;
+    float t1, t2;
+    if (g.mode == 1) { t1 = o[e]; t2 = o[e] * o[e]; }
+    else {
+      const float xh = (x[e] - c.mean[hi]) * c.rstd[hi];
+      float v = o[e];
+      if (g.mode == 3) {
+        const float y = c.gam[e] * xh + c.bet[e];
+        v *= c.gam[e] * (g.silu ? dsilu_(y) : 1.f);
+      }
+      t1 = v; t2 = xh * v;
+    }
+    if (hi) { a.s[2] += t1; a.s[3] += t2; } else { a.s[0] += t1; a.s[1] += t2; }
+  }
+}
+// after the last slab of the wave's strip: fold the RPI lanes of each column, lane r0 = 0 stores.  rb_idx = strip index (mstrip0 / strip rows)
+template <int WN>
+__device__ __forceinline__ void gs_finish(const GemmArgs& p, GsAcc& a, int lane, int wave, long rb_idx, int n0) {
+  constexpr int CPR = WN / 8;
+  const int c8 = lane % CPR, n = n0 + (wave & 1) * WN + c8 * 8;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = a.s[q];
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    a.s[q] = v;
+  }
+  if (lane < CPR && n + 8 <= p.N)
+    *reinterpret_cast<float4*>(p.gs.part + (rb_idx * (p.N >> 3) + (n >> 3)) * 4) = make_float4(a.s[0], a.s[1], a.s[2], a.s[3]);
+}
+
 template <int FL, int WN, int SLD, int EPI>
 __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0, int n0,
-                                     long slab_idx) {
+                                     long slab_idx, GsAcc* gsa = nullptr, const GsCtx<FL>* gsc = nullptr) {
   constexpr int CPR = WN / 8;
   const int wx = wave & 1;
   const float* stage = smem_f + wave * 32 * SLD;
@@ -244,15 +311,17 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
       Vec<float>::load(p.bias + n + 4, b8 + 4);
     }
     constexpr int BT = ITEMS > 4 ? 4 : ITEMS;
+    const bool gs_on = EPI == EPI_PLAIN && gsa && p.gs.mode;     // uniform over the launch
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += BT) {
-      uint4 rr[BT], ro[BT], rb[BT];
+      uint4 rr[BT], ro[BT], rb[BT], rx[BT];
 #pragma unroll
       for (int u = 0; u < BT; ++u) {
         const int mc = min(mrow0 + (it0 + u) * RPI + r0, p.M - 1);
         if (R) rr[u] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + n);
         if (p.accumulate) ro[u] = *reinterpret_cast<const uint4*>(C + (long)mc * p.ldc + n);
         if (p.rowbias) rb[u] = *reinterpret_cast<const uint4*>((const bf16*)p.rowbias + (long)((mc / p.rows_per_sample) / p.rowbias_div) * p.N + n);
+        if (gs_on && p.gs.mode >= 2) rx[u] = *reinterpret_cast<const uint4*>(gsc->xrow + (long)(mc % p.gs.HW) * p.N);   // primal row of the statistics
       }
 #pragma unroll
       for (int u = 0; u < BT; ++u) {
@@ -282,7 +351,14 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t8[e];
         }
-        H16<FL>::store8(C + (long)m * p.ldc + n, v);
+        if (gs_on) {                                 // statistics of the values as stored (what the consumer GroupNorm reads back)
+          const bf16x8 pk = H16<FL>::pack8(v);
+          *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = pk;
+          H16<FL>::load8(reinterpret_cast<const bf16*>(&pk), t8);
+          gs_add<FL>(p.gs, *gsc, t8, rx[u], *gsa);
+        } else {
+          H16<FL>::store8(C + (long)m * p.ldc + n, v);
+        }
       }
     }
   } else {

@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
 
   // ---- epilogue through LDS (same scheme as gemm_kernel)
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat, epilogue.h): plain epilogue, unsplit launches only
+  const bool gs_on = EPI == EPI_PLAIN && p.gs.mode && p.splitk <= 1;
+  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_begin<FL>(p, m0 + wy * WM, min(n0 + wx * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc); }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -233,9 +236,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
     epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0,
-                               (long)blockIdx.z * gridDim.y + blockIdx.y);
+                               (long)blockIdx.z * gridDim.y + blockIdx.y, gs_on ? &gsa : nullptr, &gsc);
     __syncthreads();
   }
+  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * WM) / WM, n0); }
 }
 
 template <int BM, int BN, int S, int FL>

@@ -219,6 +219,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 
   // ---- epilogue through LDS: the staging layout and the slab writer of the ring kernels (epilogue.h)
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat, epilogue.h): unsplit launches only
+  const bool gs_on = p.gs.mode && p.splitk <= 1;
+  if (gs_on) gs_begin<FL>(p, m0 + wy * 64, min(n0 + (wave & 1) * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -226,9 +229,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    epilogue_slab<FL, WN, SLD, EPI_PLAIN>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * 64 + i * 32, n0, (long)ksplit);
+    epilogue_slab<FL, WN, SLD, EPI_PLAIN>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * 64 + i * 32, n0, (long)ksplit,
+                                           gs_on ? &gsa : nullptr, &gsc);
     __syncthreads();
   }
+  if (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * 64) / 64, n0);
 }
 
 // 3x3, stride 1, pad 1, forward gather or its adjoint; whole image rows (or whole small images) per tile; 64-channel chunks

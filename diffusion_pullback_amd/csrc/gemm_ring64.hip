@@ -283,6 +283,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     return;
   }
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat): plain epilogue, unsplit launches only
+  const bool gs_on = EPI == EPI_PLAIN && p.gs.mode && p.splitk <= 1;
+  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_begin<FL>(p, m0 + wy * WM, min(n0 + wx * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc); }
   static_for<0, TM>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -297,10 +300,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
       // staged rows: wave pair wy holds tile rows wy*WM + i*32 .. +31; epilogue_ln's row index wy*32 + row maps to tile row wy*WM + i*32 + row
       epilogue_ln<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + i * 32 + (wave >> 1) * (WM - 32), lnq[i]);
     } else {
-      epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb);
+      epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb,
+                                       gs_on ? &gsa : nullptr, &gsc);
     }
     __syncthreads();
   });
+  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * WM) / WM, n0); }
 }
 
 template <int BM, int BN, int S, int WAVES, int FL>

@@ -83,7 +83,8 @@ class _EditBase(object):
         (``per_sample`` = 2 under classifier-free guidance, which doubles the U-Net batch).  Samples are independent, so the
         batching is not observable in the result."""
         cap = getattr(getattr(self.unet, "engine", None), "max_batch", None)
-        bound = self.memory_bound if cap is None else max(1, min(self.memory_bound, cap // per_sample))
+        want = max(self.memory_bound, getattr(self, "trajectory_batch", 0))      # trajectory batching (below) raises the bound on purpose
+        bound = want if cap is None else max(1, min(want, cap // per_sample))
         return list(x.split(bound))
 
     _phase = "U-Net forward (other)"
@@ -103,6 +104,10 @@ class EditStableDiffusion(_EditBase):
     def __init__(self, args, unet=None, vae=None, prompt_encoder=None, dataset=None, scheduler=None):
         self.seed = args.seed
         self.memory_bound = getattr(args, "memory_bound", 5)
+        # > 1: the 2 * vis_num_pc independent (pc, +-) edits of run_edit_local_encoder_pullback_zt advance TOGETHER -- their x-space-guidance chains
+        # in one U-Net call per step, their decode trajectories in one batch -- instead of one after another as edit.py:276-307 does.  Samples are
+        # independent in every kernel, so files, names and tensors are the same; the GPU sees 4x fewer, 4x fatter launches.  0 / 1: the reference's order.
+        self.trajectory_batch = int(getattr(args, "trajectory_batch", 0) or 0)
         self.unet = unet
         self.vae = vae
         self.dtype = getattr(args, "dtype", torch.float32)
@@ -203,12 +208,18 @@ class EditStableDiffusion(_EditBase):
                     noise_pred = self._eps(lat, t, self.for_prompt_emb.repeat(lat.size(0), 1, 1))
                 outs.append(self.scheduler.step(noise_pred, t, lat, eta=0).prev_sample)
             latents = torch.cat(outs, dim=0)
+        if kwargs.get("finish", True) is False:                                                 # batched trajectories: the caller finishes each experiment
+            return latents
+        return self._finish_decode(latents, self.EXP_NAME)
+
+    def _finish_decode(self, latents, exp_name):
+        """edit.py:476-482: latents / 0.18215 -> VAE decode -> clamp -> one PNG row per experiment."""
         latents = 1 / 0.18215 * latents
         with T.phase("VAE decode"):
             x0 = self.vae.decode(latents) if self.vae is not None else latents
             x0 = (x0 / 2 + 0.5).clamp(0, 1) if self.vae is not None else x0
         with T.phase("image files (PNG encode + write)"):
-            save_image(x0, os.path.join(self.result_folder, f"x0_gen-{self.EXP_NAME}.png"), nrow=x0.size(0))
+            save_image(x0, os.path.join(self.result_folder, f"x0_gen-{exp_name}.png"), nrow=x0.size(0))
         return latents
 
     @torch.no_grad()
@@ -257,6 +268,8 @@ class EditStableDiffusion(_EditBase):
         vT = vT / vT.norm(dim=1, keepdim=True)
         original_zt = zt.clone()
         results = []
+        if self.trajectory_batch > 1:
+            return self._edit_trajectories_together(idx, op, block_idx, vis_num, vis_num_pc, vT, original_zt, zT.shape[1:])
         for pc_idx in range(vis_num_pc):
             for direction in [1, -1]:
                 tag = "pos" if direction == 1 else "neg"
@@ -273,6 +286,48 @@ class EditStableDiffusion(_EditBase):
                 zt = torch.cat(zt_list, dim=0)
                 zt = zt[::(zt.size(0) // vis_num)]                                              # edit.py:301-302
                 results.append(self.DDIMforwardsteps(zt, t_start_idx=self.edit_t_idx, t_end_idx=-1))
+        return results
+
+    def _edit_trajectories_together(self, idx, op, block_idx, vis_num, vis_num_pc, vT, original_zt, lat_shape):
+        """The loop body of edit.py:276-307 for all pending (pc, +-) experiments at once (self.trajectory_batch > 1): same experiments, names, skips and
+        results; the n chains of x-space guidance take ONE U-Net call of batch 2 n per step ([z_1..z_n | z_1 + s v_1 .. z_n + s v_n]) and the n * (vis_num + 1)
+        decode trajectories ONE call of that batch per DDIM step (further split only by the engine's batch limit)."""
+        todo = []
+        for pc_idx in range(vis_num_pc):
+            for direction in [1, -1]:
+                tag = "pos" if direction == 1 else "neg"
+                name = f"Edit_zt-{self.dataset_name}_{idx}-edit_{self.edit_t}T-{op}-block_{block_idx}-pc_{pc_idx:0=3d}_{tag}-edit_prompt_{self.edit_prompt}"
+                if os.path.exists(os.path.join(self.result_folder, name + ".png")):
+                    print("!!!ALREADY DONE EXP!!!")
+                    continue
+                todo.append((name, direction * vT[pc_idx, :].view(-1, *lat_shape)))
+        if not todo:
+            return []
+        n = len(todo)
+        t = self.scheduler.timesteps[self.edit_t_idx]
+        self._phase = "x-space guidance: batch-2 U-Net forwards"
+        vk = torch.cat([v for _, v in todo], dim=0)                                             # [n, C, H, W]
+        z = original_zt.repeat(n, 1, 1, 1)
+        chain = [z]
+        cap = getattr(getattr(self.unet, "engine", None), "max_batch", None) or 2 * n
+        per = max(1, min(n, cap // 2))                                                          # chains per U-Net call
+        for _ in range(self.x_space_guidance_num_step):
+            nxt = []
+            for zc, vc in zip(z.split(per), vk.split(per)):
+                m = zc.size(0)
+                et = self._eps(torch.cat([zc, zc + self.x_space_guidance_edit_step * vc], dim=0), t, self.edit_prompt_emb.repeat(2 * m, 1, 1))   # edit.py:490
+                et_null, et_edit = et.chunk(2)
+                nxt.append(zc + self.x_space_guidance_scale * (et_edit - et_null))              # edit.py:501
+            z = torch.cat(nxt, dim=0)
+            chain.append(z)
+        steps = torch.stack(chain, dim=1)                                                       # [n, num_step + 1, C, H, W]
+        picked = steps[:, ::(steps.size(1) // vis_num)]                                         # edit.py:301-302, per chain
+        m = picked.size(1)
+        lat = self.DDIMforwardsteps(picked.reshape(n * m, *lat_shape), t_start_idx=self.edit_t_idx, t_end_idx=-1, finish=False)
+        results = []
+        for i, (name, _) in enumerate(todo):
+            self.EXP_NAME = name
+            results.append(self._finish_decode(lat[i * m:(i + 1) * m], name))
         return results
 
 

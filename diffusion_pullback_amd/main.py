@@ -56,6 +56,9 @@ _FLAGS = [  # (name, type, default) -- define_argparser.py:20-110, live path onl
     ("pca_rank", int, 2), ("op", str, "mid"), ("block_idx", int, 0), ("vis_num", int, 4), ("vis_num_pc", int, 2), ("weights", str, ""),
     ("net_scale", str, "full"), ("vae", str, "none"), ("text_encoder", str, "none"), ("tokenizer_dir", str, ""),
     ("timing", str2bool, False),      # wall-clock breakdown of the run by phase (timing.py; synchronises at phase boundaries)
+    # U-Net batch of the edit trajectories: the 2 * vis_num_pc independent (pc, +-) edits of edit.py:276-307 run together (x-space guidance as one batch-2n call per
+    # step, the n * (vis_num + 1) decode trajectories as one batch).  Same files and tensors; 0 / 1 = one experiment after another, memory_bound latents per call
+    ("trajectory_batch", int, 20),
 ]
 
 
@@ -116,6 +119,10 @@ def build_unet(args) -> PullbackUNet:
     small = args.net_scale != "full"
     # U-Net batch: memory_bound latents of the decode loop (x2 under classifier-free guidance), never below the 2 of x-space guidance
     max_batch = max(2, min(args.memory_bound, args.vis_num + 1) * (2 if args.guidance_scale > 1.0 else 1))
+    if getattr(args, "trajectory_batch", 0) > 1 and args.is_stable_diffusion and args.run_edit_local_encoder_pullback_zt:
+        # 2 * vis_num_pc chains together: batch 4 * vis_num_pc for the guidance step, 2 * vis_num_pc * (vis_num + 1) decode trajectories
+        max_batch = max(max_batch, min(args.trajectory_batch, 2 * args.vis_num_pc * (args.vis_num + 1)) * (2 if args.guidance_scale > 1.0 else 1),
+                        min(args.trajectory_batch, 4 * args.vis_num_pc))
     if args.is_stable_diffusion:
         cfg = cf.sd_config_for(args.model_name)           # SD-v1.x or SD-2(.1)-base; anything else raises
         if small:

@@ -217,10 +217,13 @@ def test_uncond_driver_matches_reference_driver_fixture(tmp_path, monkeypatch):
     print("uncond driver: worst relative U-Net input error", worst, "flipped", flipped)
 
 
-def test_sd_driver_matches_reference_driver_fixture(tmp_path, monkeypatch):
+@pytest.mark.parametrize("trajectory_batch", [0, 10], ids=["one_experiment_at_a_time", "trajectories_together"])
+def test_sd_driver_matches_reference_driver_fixture(tmp_path, monkeypatch, trajectory_batch):
     """Rows a10-a13, SD variant: EditStableDiffusion on the HIP engine against the reference's class driving a toy SD-style net with
     fixed prompt embeddings / VAE stand-ins: inversion under the inversion prompt, forward under the forward prompt, guidance under
-    the edit prompt (edit.py:112-183, :385-502, :185-307)."""
+    the edit prompt (edit.py:112-183, :385-502, :185-307).  trajectory_batch = 0: the reference's order, every U-Net input compared call by call;
+    = 10 (round 4, the CLI default is 20): the (pc, +-) experiments advance together -- guidance as one batch-4 call per step, the 2 x 5 decode
+    trajectories as one batch-10 call per step -- and must hand the same tensors to save_image under the same names."""
     from diffusion_pullback_amd import PullbackUNet, configs as cf
     from diffusion_pullback_amd import edit as E
     from diffusion_pullback_amd import main as m
@@ -229,8 +232,8 @@ def test_sd_driver_matches_reference_driver_fixture(tmp_path, monkeypatch):
     a = f["args"]
     cfg = unet_sd.SDConfig(**f["cfg"])
     params = cf.sd_init_params(cfg, seed=f["seed"], gain=f["gain"], spectrum=cf.Spectrum(**f["spectrum"]))
-    net = _Rec(PullbackUNet("sd", cfg, params, dtype=torch.float32, device=DEV, max_batch=5, max_rank=2, verbose=False))
-    argv = ["--note", "t", "--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Examples", "--result_folder", str(tmp_path), "--device", DEV,
+    net = _Rec(PullbackUNet("sd", cfg, params, dtype=torch.float32, device=DEV, max_batch=max(5, trajectory_batch), max_rank=2, verbose=False))
+    argv = ["--note", "t", "--trajectory_batch", str(trajectory_batch), "--model_name", "runwayml/stable-diffusion-v1-5", "--dataset_name", "Examples", "--result_folder", str(tmp_path), "--device", DEV,
             "--edit_prompt", "sitting dog", "--x_space_guidance_scale", str(a["x_space_guidance_scale"]), "--x_space_guidance_num_step",
             str(a["x_space_guidance_num_step"]), "--x_space_guidance_edit_step", str(a["x_space_guidance_edit_step"]), "--edit_t", str(a["edit_t"]),
             "--for_steps", str(a["for_steps"]), "--inv_steps", str(a["inv_steps"]), "--net_scale", "small", "--pca_rank", "2"]
@@ -254,7 +257,20 @@ def test_sd_driver_matches_reference_driver_fixture(tmp_path, monkeypatch):
     flipped = bool((vT[0].cpu() * f["vT"][0]).sum() < 0)
     n_pre = (a["inv_steps"] - 2) + f["edit_t_idx"]
     blk = a["x_space_guidance_num_step"] + (a["for_steps"] - 1 - f["edit_t_idx"])
-    worst = _compare_trace(net.calls, f, flipped, n_pre, blk, 2e-3)
+    if trajectory_batch > 1:
+        # the same experiments in fewer, fatter U-Net calls: the shared prefix call by call, then 8 guidance calls of batch 4 and 11 decode calls of batch 10
+        nG, nD = a["x_space_guidance_num_step"], a["for_steps"] - 1 - f["edit_t_idx"]
+        assert len(net.calls) == n_pre + nG + nD and [c[1].shape[0] for c in net.calls[n_pre:]] == [4] * nG + [10] * nD
+        worst = max(rel(x, f["trace_x"][i]) for i, (t, x) in enumerate(net.calls[:n_pre]))
+        first = 1 if flipped else 0          # the product's first chain ('+v') is the reference's second block when the vector's sign is flipped
+        for s_ in range(nG):                 # rows [z_+, z_-, z_+ + s v, z_- - s v] of guidance call s_ against the two reference batch-2 calls
+            x = net.calls[n_pre + s_][1]
+            for c in range(2):
+                ref = f["trace_x"][n_pre + ((c + first) % 2) * blk + s_]
+                worst = max(worst, rel(torch.stack([x[c], x[2 + c]]), ref))
+        assert worst < 2e-3, worst
+    else:
+        worst = _compare_trace(net.calls, f, flipped, n_pre, blk, 2e-3)
     ref_saved, got = dict(f["saved"]), dict(saved)
     for tag, rtag in (("pos", "neg" if flipped else "pos"), ("neg", "pos" if flipped else "neg")):
         n = f"x0_gen-Edit_zt-Examples_5-edit_0.7T-mid-block_0-pc_000_{tag}-edit_prompt_tiger.png"
