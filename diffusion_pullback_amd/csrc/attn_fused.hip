@@ -997,6 +997,7 @@ struct CrossArgs {
   const bf16* BT;                     // per-head transpose of the second-stage operand B: [B][H][d][Lkp]
   const bf16* X; bf16* Y;             // [nt][L][Cx] in, [nt][L][Cy] out
   int L, Lk, Lkp, C, Ck, Cx, Cy, H, kps, a_is_v, accumulate, xcd;
+  int primal;                         // 1: Y = P V (the forward pass itself: no X, no delta); BT may be null -- B^T is then built in LDS from the row tile
   float scale, c_in, c_out;
 };
 constexpr int XKEYS = 96, XLDT = XKEYS + 4;
@@ -1025,19 +1026,32 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
       *reinterpret_cast<uint4*>(sV + r * F::LDR + cc) = vv;
     }
     constexpr int CPT = XKEYS / 8;
-    const bf16* Bp = a.BT + ((long)b * a.H + h) * D * a.Lkp;
-    for (int c = tid; c < F::DO * CPT; c += nthr) {
-      const int r = c / CPT, cc = (c % CPT) * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (r < D && cc < a.Lkp) v = *reinterpret_cast<const uint4*>(Bp + (long)r * a.Lkp + cc);
-      bf16* dst = sBT + r * XLDT + cc;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
-      *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
+    if (a.BT) {
+      const bf16* Bp = a.BT + ((long)b * a.H + h) * D * a.Lkp;
+      for (int c = tid; c < F::DO * CPT; c += nthr) {
+        const int r = c / CPT, cc = (c % CPT) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < D && cc < a.Lkp) v = *reinterpret_cast<const uint4*>(Bp + (long)r * a.Lkp + cc);
+        bf16* dst = sBT + r * XLDT + cc;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
+      }
+    } else {
+      // no transposed copy in HBM (forward pass): B^T [DO][96] straight from the 77 global rows of B, 8 head-dim values per 16-byte load
+      const bf16* Bp = (a.a_is_v ? a.K : a.V) + (long)b * a.Lk * a.Ck + h * D;
+      for (int c = tid; c < XKEYS * (F::DO / 8); c += nthr) {
+        const int r = c % XKEYS, cc = (c / XKEYS) * 8;            // consecutive lanes: consecutive keys -> conflict-free 2-byte LDS stores
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < a.Lk && cc < D) v = *reinterpret_cast<const uint4*>(Bp + (long)r * a.Ck + cc);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sBT[(cc + i) * XLDT + r].v = e[i];
+      }
     }
   }
   bf16x8 qf[F::NS], xf[F::NS];
   load_outer_frags<D>(a.Q + (long)b * a.L * a.C + (long)q * a.C + h * D, qf, lhi);
-  load_outer_frags<D>(a.X + (long)j * a.L * a.Cx + (long)q * a.Cx + h * D, xf, lhi);
+  if (!a.primal) load_outer_frags<D>(a.X + (long)j * a.L * a.Cx + (long)q * a.Cx + h * D, xf, lhi);
   __syncthreads();
   const bf16* sA = a.a_is_v ? sV : sK;
   f32x16 s[3], t[3];
@@ -1048,7 +1062,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
 #pragma unroll
     for (int stp = 0; stp < F::NS; ++stp) {
       s[kb] = MFMA(lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), qf[stp], s[kb]);
-      t[kb] = MFMA(lds_a_frag(sA, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), xf[stp], t[kb]);
+      if (!a.primal) t[kb] = MFMA(lds_a_frag(sA, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), xf[stp], t[kb]);
     }
   }
   const float c2 = a.scale * 1.44269504088896f;
@@ -1088,7 +1102,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(CrossArgs a) {
   for (int kb = 0; kb < 3; ++kb) {
     float w[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = t[kb][r] - delta * s[kb][r];
+    for (int r = 0; r < 16; ++r) w[r] = a.primal ? s[kb][r] : t[kb][r] - delta * s[kb][r];
     bf16x8 wb[2];
     pack_b<FL>(w, wb);
 #pragma unroll
@@ -1142,6 +1156,8 @@ int launch_attn_cross(const CrossAttnArgs& f, int nt, hipStream_t st) {
   a.L = f.L; a.Lk = f.Lk; a.Lkp = f.Lkp; a.C = f.C; a.Ck = f.Ck; a.Cx = f.Cx; a.Cy = f.Cy; a.H = f.H; a.kps = f.kps;
   a.a_is_v = f.adjoint; a.accumulate = f.accumulate; a.scale = f.scale; a.xcd = 0;   // every block loads its own small K/V tile: nothing to share
   a.c_in = f.adjoint ? 1.f : f.scale; a.c_out = f.adjoint ? f.scale : 1.f;
+  a.primal = f.primal;
+  if (f.primal) { a.a_is_v = 0; a.c_in = 1.f; a.c_out = 1.f; a.accumulate = 0; }
   const int waves = f.L >= 128 ? 4 : f.L / 32;
   dim3 grid(f.L / (waves * 32), nt * f.H);
   if (!head_dim_ok(f.d)) { set_error("cross attention: head dim %d unsupported", f.d); return -1; }

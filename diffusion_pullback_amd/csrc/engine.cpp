@@ -161,6 +161,8 @@ void prof_close(dpb_engine* e, int idx) {
   if (idx >= 0) (void)hipEventRecord(e->prof[idx].b, e->stream);
 }
 
+// one-launch forward of the text-conditioned attention layers (A/B switch: DPB_CROSS_PRIMAL=0, dpb_debug_set("cross_primal", 0): the materialised path)
+int g_cross_primal = getenv("DPB_CROSS_PRIMAL") ? atoi(getenv("DPB_CROSS_PRIMAL")) : 1;
 // GroupNorm statistics from the producer's epilogue (A/B switch: DPB_GN_EPI_STATS=0, dpb_debug_set("gn_epi_stats", 0): every two-pass GroupNorm runs its own statistics launch)
 int g_gn_epi_stats = getenv("DPB_GN_EPI_STATS") ? atoi(getenv("DPB_GN_EPI_STATS")) : 1;
 
@@ -241,7 +243,7 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
   if (mode == 0) {
     g.bias = (const float*)d.w[2];
     if (d.rowbias >= 0) {
-      g.rowbias = e->P(d.rowbias);
+      g.rowbias = e->P(d.rowbias) + (size_t)d.ip[10] * e->es;      // ip[10]: column window of a net-wide fused projection (tape.py shared_begin)
       g.rows_per_sample = bo.rows;
       g.rowbias_div = 1 << 30;
     }
@@ -558,6 +560,24 @@ int attn_primal(dpb_engine* e, const Op& op, int B) {
     prof_close(e, pi);
     return r;
   }
+  if (p.cross && g_cross_primal) {
+    // text-conditioned layers: O = softmax(scale Q K^T) V in ONE launch (the 77 keys fit one masked tile; V^T is built in LDS), instead of
+    // GEMM + softmax + transpose + GEMM; the tangent / adjoint kernels of the pullback passes still read the per-head V^T / K^T copies
+    CrossAttnArgs f;
+    f.Q = x.Q; f.K = x.K; f.V = x.V; f.BT = nullptr; f.X = nullptr; f.Y = x.O;
+    f.L = p.Lq; f.Lk = p.Lk; f.Lkp = p.Lkp; f.C = x.ldq; f.Ck = x.ldk; f.Cx = x.ldq; f.Cy = x.ldo;
+    f.H = H; f.d = p.d; f.kps = 1; f.primal = 1; f.scale = scale; f.fl = e->dtype == DT_F16;
+    e->n_launch++;
+    const double fl = 2.0 * p.Lq * (double)p.Lk * p.d * 2 * B * H;
+    e->flops += fl;
+    const int pi = prof_open(e, fl, 10, p.Lq, p.Lk, p.d, B * H, 2);
+    const int r = launch_attn_cross(f, B, e->stream);
+    prof_close(e, pi);
+    if (r || e->fwd_only) return r;
+    e->n_launch += 2;
+    if (int r2 = launch_transpose(e->dtype, x.V, ws + p.VT, B, H, (long)p.Lk * x.ldv, p.d, p.Lk, p.d, x.ldv, p.Lkp, (long)p.d * p.Lkp, e->stream)) return r2;
+    return launch_transpose(e->dtype, x.K, ws + p.KT, B, H, (long)p.Lk * x.ldk, p.d, p.Lk, p.d, x.ldk, p.Lkp, (long)p.d * p.Lkp, e->stream);
+  }
   GemmArgs g;   // S = scale * Q K^T
   g.A = x.Q; g.lda = x.ldq; g.sA1 = (long)p.Lq * x.ldq; g.sA2 = p.d;
   g.B = x.K; g.ldb = x.ldk; g.sB1 = (long)p.Lk * x.ldk; g.sB2 = p.d;
@@ -848,6 +868,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
     if (d.kind == DPB_OP_CONV) {
       if (d.res >= 0) { if (!okb(d.res)) return bad("bad res", i); c = c && e->bufs[d.res].is_const; }
       if (d.rowbias >= 0 && (!okb(d.rowbias) || e->bufs[d.rowbias].kind != DPB_BUF_SHARED)) return bad("rowbias must be a SHARED buffer", i);
+      if (d.rowbias >= 0 && (d.ip[10] < 0 || d.ip[10] % 8 || d.ip[10] + round8(d.ip[5]) > e->bufs[d.rowbias].C)) return bad("bad rowbias column window", i);
       if (!d.w[0]) return bad("missing weight", i);
       if (d.ip[2] != e->bufs[d.in0].C || e->bufs[d.out].C != round8(d.ip[5])) return bad("conv channel mismatch", i);
     }
@@ -1315,6 +1336,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "lazy_reduce")) { g_lazy_reduce = value; return 0; }
   else if (!strcmp(key, "ln_fuse")) { g_ln_fuse = value; return 0; }
   else if (!strcmp(key, "gn_epi_stats")) { g_gn_epi_stats = value; return 0; }
+  else if (!strcmp(key, "cross_primal")) { g_cross_primal = value; return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

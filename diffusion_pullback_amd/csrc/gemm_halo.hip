@@ -141,6 +141,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int wy = wave >> 1, wx = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat, epilogue.h): unsplit launches; constants fetched under the K loop
+  const bool gs_on = p.gs.mode && p.splitk <= 1;
+  if (gs_on) gs_begin<FL>(p, m0 + wy * 64, min(n0 + wx * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc);
   int pixm[2];                                                            // halo pixel of the CENTRE tap for this lane's two A-fragment rows
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -219,9 +222,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 
   // ---- epilogue through LDS: the staging layout and the slab writer of the ring kernels (epilogue.h)
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
-  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat, epilogue.h): unsplit launches only
-  const bool gs_on = p.gs.mode && p.splitk <= 1;
-  if (gs_on) gs_begin<FL>(p, m0 + wy * 64, min(n0 + (wave & 1) * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll

@@ -201,6 +201,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     for (int i = 0; i < NIB; ++i) kcb[i] += BK;
   };
 
+  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat): plain epilogue, unsplit launches; constants fetched here, under the K loop
+  const bool gs_on = EPI == EPI_PLAIN && p.gs.mode && p.splitk <= 1;
+  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_begin<FL>(p, m0 + (wave >> 1) * WM, min(n0 + (wave & 1) * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc); }
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -283,9 +286,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     return;
   }
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
-  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat): plain epilogue, unsplit launches only
-  const bool gs_on = EPI == EPI_PLAIN && p.gs.mode && p.splitk <= 1;
-  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_begin<FL>(p, m0 + wy * WM, min(n0 + wx * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc); }
   static_for<0, TM>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
 #pragma unroll

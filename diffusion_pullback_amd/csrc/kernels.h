@@ -161,6 +161,7 @@ struct CrossAttnArgs {
   const void* BT = nullptr;                              // per-head transpose [B][H][d][Lkp] of V (tangent) or K (adjoint)
   const void* X = nullptr; void* Y = nullptr;            // dQ -> dO (tangent) or gO -> gQ (adjoint)
   int L = 0, Lk = 0, Lkp = 0, C = 0, Ck = 0, Cx = 0, Cy = 0, H = 0, d = 0, kps = 1, adjoint = 0, accumulate = 0, fl = 0;
+  int primal = 0;                                        // 1: the forward pass itself, Y = softmax(scale Q K^T) V (X unused; BT may be null: built in LDS)
   float scale = 1.f;
 };
 int cross_attention_supported(int dtype, int d, int Lq, int Lk, int kv_const);

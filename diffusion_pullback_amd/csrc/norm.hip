@@ -105,14 +105,22 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
       const int c_lo = g * cpg / CH, c_hi = (g * cpg + cpg - 1) / CH;
       const int b0 = (int)((long)nrb * q / 4), b1 = (int)((long)nrb * (q + 1) / 4);
       double acc = 0.0;
-      for (int bb = b0; bb < b1; bb += 8) {
-        for (int c = c_lo; c <= c_hi; ++c) {
-          const int slot = (c * CH / cpg == g) ? 0 : 2;
-          float v[8];
+      // 16 row blocks x 3 chunk columns = 48 clamped loads in flight per round (one round for the 64x64 / 32x32 maps of SD at cpg = 10; a dependent
+      // round trip per (8 row blocks, column) made this prologue cost more than the statistics launch it replaces), added in (row block, column) order
+      for (int bb = b0; bb < b1; bb += 16) {
+        for (int c0 = c_lo; c0 <= c_hi; c0 += 3) {
+          float v[3][16];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = pj[((long)min(bb + u, b1 - 1) * ncc + c) * 4 + slot + w];   // clamped loads, all in flight
+          for (int cc = 0; cc < 3; ++cc) {
+            const int c = min(c0 + cc, c_hi);
+            const int slot = (c * CH / cpg == g) ? 0 : 2;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) acc += bb + u < b1 ? (double)v[u] : 0.0;
+            for (int u = 0; u < 16; ++u) v[cc][u] = pj[((long)min(bb + u, b1 - 1) * ncc + c) * 4 + slot + w];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) acc += (bb + u < b1 && c0 + cc <= c_hi) ? (double)v[cc][u] : 0.0;
         }
       }
       lseg[q][i] = acc;

@@ -97,7 +97,7 @@ class Tape:
 
     def conv(self, name: str, x: int, hw: Tuple[int, int], cout: int, ks: int = 3, stride: int = 1, pad: int = 1,
              upsample: bool = False, res: int = -1, rowbias: int = -1, need_adj: bool = True, kind: int = L.BUF_ACT,
-             interleave: int = 0) -> int:
+             interleave: int = 0, rowbias_off: int = 0) -> int:
         """3x3 / strided / upsampling convolution, 1x1 convolution or Linear (ks=1)."""
         rows, cin_p, _ = self.buffers[x]
         h, w = hw
@@ -113,8 +113,35 @@ class Tape:
         out = self.buf(ho * wo if ks != 1 else rows, cout_p, kind, cout if cout != cout_p else 0)
         pf, pa, pb = self._conv_w(name, cin_p, cout_p, need_adj, interleave)
         self._op(kind=L.OP_CONV, in0=x, out=out, res=res, rowbias=rowbias,
-                 ip=[h, w, cin_p, ho, wo, cout, ks, stride, pad, gather, 0, 0], w=[pf, pa, pb, 0])
+                 ip=[h, w, cin_p, ho, wo, cout, ks, stride, pad, gather, rowbias_off, 0], w=[pf, pa, pb, 0])
         return out
+
+    # ------------------------------------------------------------- projections of one x-independent input, fused across the whole net
+    def shared_begin(self, src: int, kind: int) -> dict:
+        """Every ResBlock projects the SAME SiLU(time embedding) and every cross-attention layer projects the SAME prompt context: instead of one
+        small GEMM per layer (22 + 16 launches per SD-1.5 forward) their weights are concatenated along Cout into ONE product, issued where the
+        input becomes available; the consumers read column windows of its output (rowbias column offset / attention k, v offsets).  The width is
+        known only when the build stops (``upto``), so the op is created by shared_end and inserted at this position of the tape."""
+        rows = self.buffers[src][0]
+        return dict(src=src, kind=kind, pos=len(self.ops), names=[], width=0, out=self.buf(rows, 8, kind))
+
+    def shared_add(self, h: dict, names, cout: int) -> int:
+        """-> column offset of this layer's ``cout`` outputs inside the fused product"""
+        assert cout % 8 == 0, cout
+        off = h["width"]
+        h["names"] += list(names) if isinstance(names, tuple) else [names]
+        h["width"] += cout
+        return off
+
+    def shared_end(self, h: dict) -> None:
+        if not h["names"]:                        # nothing uses it (prefix builds): leave a tiny unused buffer, no op
+            return
+        rows, cin_p, _ = self.buffers[h["src"]]
+        self.buffers[h["out"]] = (rows, h["width"], h["kind"])
+        pf, pa, pb = self._conv_w(tuple(h["names"]), cin_p, h["width"], False)
+        d = dict(kind=L.OP_CONV, in0=h["src"], in1=-1, in2=-1, out=h["out"], res=-1, rowbias=-1,
+                 ip=[1, 1, cin_p, 1, 1, h["width"], 1, 1, 1, L.GATHER_NONE, 0, 0], fp=[0.0] * 4, w=[pf, pa, pb, 0])
+        self.ops.insert(h["pos"], d)
 
     def groupnorm(self, name: str, x: int, groups: int, eps: float, silu: bool) -> int:
         rows, c, _ = self.buffers[x]
@@ -178,6 +205,13 @@ class Tape:
 
 # =================================================================== DDPM (pixel space, unconditional)
 def build_ddpm(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None) -> Tape:
+    t = _build_ddpm(cfg, params, dtype, device, upto)
+    for h in t._deferred:
+        t.shared_end(h)
+    return t
+
+
+def _build_ddpm(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None) -> Tape:
     """cfg: any object with the fields of oracle.unet_ddpm.DDPMConfig (ch, ch_mult, num_res_blocks,
     attn_resolutions, in_channels, out_ch, resolution, groups, gn_eps).  ``upto=(op, idx)`` stops
     building after that tap (weights beyond it are not uploaded)."""
@@ -188,12 +222,13 @@ def build_ddpm(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = Non
     e0 = t.conv("temb.dense.0", t.temb_in, (1, 1), cfg.temb_ch, ks=1, need_adj=False, kind=L.BUF_SHARED)
     e1 = t.conv("temb.dense.1", t.silu(e0), (1, 1), cfg.temb_ch, ks=1, need_adj=False, kind=L.BUF_SHARED)
     st = t.silu(e1)
+    tproj = t.shared_begin(st, L.BUF_SHARED)       # every ResBlock's temb_proj in one product
+    t._deferred = [tproj]
     t.x = t.buf(res * res, _r8(cfg.in_channels))
 
     def resblock(pre, x, cin, cout, r):
         n1 = t.groupnorm(pre + ".norm1", x, G, eps, True)
-        rb = t.conv(pre + ".temb_proj", st, (1, 1), cout, ks=1, need_adj=False, kind=L.BUF_SHARED)
-        c1 = t.conv(pre + ".conv1", n1, (r, r), cout, rowbias=rb)
+        c1 = t.conv(pre + ".conv1", n1, (r, r), cout, rowbias=tproj["out"], rowbias_off=t.shared_add(tproj, pre + ".temb_proj", cout))
         n2 = t.groupnorm(pre + ".norm2", c1, G, eps, True)
         sc = t.conv(pre + ".nin_shortcut", x, (r, r), cout, ks=1) if cin != cout else x
         return t.conv(pre + ".conv2", n2, (r, r), cout, res=sc)
@@ -254,6 +289,13 @@ def build_ddpm(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = Non
 
 # =================================================================== Stable Diffusion (latent space, text conditioned)
 def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None) -> Tape:
+    t = _build_sd(cfg, params, dtype, device, upto)
+    for h in t._deferred:
+        t.shared_end(h)
+    return t
+
+
+def _build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None) -> Tape:
     """cfg: fields of oracle.unet_sd.SDConfig.  ('down', i) taps follow the intended semantics of the
     reference (output of the block after its downsampler; utils.py:489-490)."""
     t = Tape(params, dtype, device)
@@ -264,13 +306,15 @@ def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None)
     e0 = t.conv("time_embedding.linear_1", t.temb_in, (1, 1), cfg.temb_ch, ks=1, need_adj=False, kind=L.BUF_SHARED)
     e1 = t.conv("time_embedding.linear_2", t.silu(e0), (1, 1), cfg.temb_ch, ks=1, need_adj=False, kind=L.BUF_SHARED)
     st = t.silu(e1)
+    tproj = t.shared_begin(st, L.BUF_SHARED)       # every ResBlock's time_emb_proj in one product
     t.ctx = t.buf(cfg.ctx_len, _r8(cfg.cross_dim), valid=cfg.cross_dim if cfg.cross_dim % 8 else 0)
+    kvall = t.shared_begin(t.ctx, L.BUF_ACT)       # every cross-attention layer's to_k / to_v of the prompt context in one product
+    t._deferred = [kvall, tproj]                   # (later tape position first: inserting does not shift the earlier one)
     t.x = t.buf(s * s, _r8(cfg.in_channels))
 
     def resnet(pre, x, cin, cout, r):
         n1 = t.groupnorm(pre + ".norm1", x, G, 1e-5, True)
-        rb = t.conv(pre + ".time_emb_proj", st, (1, 1), cout, ks=1, need_adj=False, kind=L.BUF_SHARED)
-        c1 = t.conv(pre + ".conv1", n1, (r, r), cout, rowbias=rb)
+        c1 = t.conv(pre + ".conv1", n1, (r, r), cout, rowbias=tproj["out"], rowbias_off=t.shared_add(tproj, pre + ".time_emb_proj", cout))
         n2 = t.groupnorm(pre + ".norm2", c1, G, 1e-5, True)
         sc = t.conv(pre + ".conv_shortcut", x, (r, r), cout, ks=1) if cin != cout else x
         return t.conv(pre + ".conv2", n2, (r, r), cout, res=sc)
@@ -284,8 +328,8 @@ def build_sd(cfg, params, dtype, device, upto: Optional[Tuple[str, int]] = None)
         h = t.conv(tb + ".attn1.to_out.0", t.attention(qkv, qkv, qkv, heads, c, (0, c, 2 * c)), (r, r), c, ks=1, res=h)
         z = t.layernorm(tb + ".norm2", h)
         q = t.conv(tb + ".attn2.to_q", z, (r, r), c, ks=1)
-        kv = t.conv((tb + ".attn2.to_k", tb + ".attn2.to_v"), t.ctx, (1, 1), 2 * c, ks=1, need_adj=False)     # fused k/v of the context
-        h = t.conv(tb + ".attn2.to_out.0", t.attention(q, kv, kv, heads, c, (0, 0, c)), (r, r), c, ks=1, res=h)
+        ko = t.shared_add(kvall, (tb + ".attn2.to_k", tb + ".attn2.to_v"), 2 * c)                             # k | v of the context: a window of the net-wide product
+        h = t.conv(tb + ".attn2.to_out.0", t.attention(q, kvall["out"], kvall["out"], heads, c, (0, ko, ko + c)), (r, r), c, ks=1, res=h)
         z = t.layernorm(tb + ".norm3", h)
         il = 64 if (4 * c) % 64 == 0 else 0                                     # a / g interleaved in 64-column blocks: GEGLU fuses into GEMM epilogues
         f = t.geglu(t.conv(tb + ".ff.net.0.proj", z, (r, r), 8 * c, ks=1, interleave=il), il)

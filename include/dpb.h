@@ -59,7 +59,7 @@ typedef struct dpb_op_desc {
   int32_t out;               /* output buffer id */
   int32_t res;               /* CONV: buffer added to the output (residual / shortcut), -1 = none */
   int32_t rowbias;           /* CONV: DPB_BUF_SHARED buffer [1][Cout] added to every row (temb projection), -1 */
-  int32_t ip[12];            /* CONV: H W Cin Ho Wo Cout KS stride pad gather ; GROUPNORM: G silu ;
+  int32_t ip[12];            /* CONV: H W Cin Ho Wo Cout KS stride pad gather rowbias_col (first column of this op's Cout-wide window in the rowbias buffer) ; GROUPNORM: G silu ;
                                 ATTENTION: heads oq ok ov causal ; GEGLU: F interleave(0|64)                                               */
   float fp[4];               /* GROUPNORM/LAYERNORM: eps */
   const void* w[4];          /* CONV: w[0]=W [Cout][KS*KS*Cin] (engine dtype), w[1]=W^T [Cin][KS*KS*Cout]

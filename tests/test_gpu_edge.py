@@ -266,7 +266,9 @@ def test_groupnorm_statistics_from_the_producer_epilogue_match_the_statistics_la
     tap = ("down", 1)
     net = PullbackUNet("sd", cf.SD15, params, dtype=dtype, device="cuda:0", max_batch=2, max_rank=10, upto=tap, verbose=False)
     e = net.engine
-    tol = 4e-3 if dtype == torch.bfloat16 else 1e-3
+    # a different summation order of the statistics flips 16-bit roundings downstream: 7e-3 (bf16) / 9e-4 (fp16) measured over the ~60 layers to the
+    # tap -- the size of the bf16 engine's own noise against the fp32 oracle (TOL 4e-2 in test_gpu_fullsize.py), 8x smaller in fp16 as a rounding effect must be
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
     try:
         for B, k in [(1, 5), (2, 5), (1, 1), (2, 1)]:
             V = torch.randn(B * k, 16384, generator=g)
