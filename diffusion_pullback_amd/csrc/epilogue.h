@@ -9,6 +9,7 @@
 //                  dy = da*G1 + dg*G2 [M][F] -- dh [M][2F] never exists in HBM, and no transcendental runs in the epilogue.
 //   EPI_GEGLU_ADJ  adjoint of GEGLU fused into the adjoint of the FF-out product: the tile holds gy for 128 hidden units; writes
 //                  ga = gy*G1 and gg = gy*G2 at their interleaved positions of gh [M][2F].
+//   EPI_GEGLU_FWD  forward pass only (dpb_forward): y = a*gelu(g) from the FF-in product, bitwise the unfused product + GEGLU kernel
 //   EPI_LN_TAN     (row-complete tile: BN = N, epilogue_ln below) h = acc (+R) -> C, and the LayerNorm tangent of h at the primal row -> C2
 //   EPI_LN_ADJ     (row-complete tile) the LayerNorm adjoint of acc (= cotangent of the LayerNorm output) (+)-> C
 #pragma once
@@ -127,11 +128,11 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& p, bf16* C, const bf
 // ---- GroupNorm statistics of the output, from the epilogue (GnStat, kernels.h).  A lane keeps its 16-byte column across the items and slabs of its
 // wave's row strip, so it sums its rows in registers (GsAcc), the RPI lanes of a column are folded by a fixed xor tree, and ONE lane per column stores
 // the strip's float4 partial: no atomics, no LDS, the same additions in the same order every run.
-struct GsAcc { float s[4] = {0.f, 0.f, 0.f, 0.f}; };
+struct GsAcc { float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f; };    // scalars, not an array: a dynamically indexed register array is demoted to scratch
 template <int FL>
 struct GsCtx {                       // per-lane constants of the statistics (filled once per wave strip: gs_begin)
   int split = 8;                     // elements e >= split of the chunk belong to the chunk's second group
-  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+  float mean0 = 0.f, mean1 = 0.f, rstd0 = 0.f, rstd1 = 0.f;
   float gam[8], bet[8];
   const bf16* xrow = nullptr;        // primal rows of this strip's sample: x + (sample * HW) * N + n
 };
@@ -144,8 +145,8 @@ __device__ __forceinline__ void gs_begin(const GemmArgs& p, int mstrip0, int n, 
     const int mm = min(mstrip0, p.M - 1);
     const int smp = (mm / g.HW) / g.kps;                       // the whole strip lies in one tangent / cotangent (HW % strip rows == 0)
     const int g1 = min(g0 + 1, g.G - 1);
-    c.mean[0] = (float)g.pstats[((long)smp * g.G + g0) * 2]; c.rstd[0] = (float)g.pstats[((long)smp * g.G + g0) * 2 + 1];
-    c.mean[1] = (float)g.pstats[((long)smp * g.G + g1) * 2]; c.rstd[1] = (float)g.pstats[((long)smp * g.G + g1) * 2 + 1];
+    c.mean0 = (float)g.pstats[((long)smp * g.G + g0) * 2]; c.rstd0 = (float)g.pstats[((long)smp * g.G + g0) * 2 + 1];
+    c.mean1 = (float)g.pstats[((long)smp * g.G + g1) * 2]; c.rstd1 = (float)g.pstats[((long)smp * g.G + g1) * 2 + 1];
     c.xrow = (const bf16*)g.x + (long)smp * g.HW * p.N + n;
     if (g.mode == 3) {
       Vec<float>::load(g.gamma + n, c.gam); Vec<float>::load(g.gamma + n + 4, c.gam + 4);
@@ -156,47 +157,104 @@ __device__ __forceinline__ void gs_begin(const GemmArgs& p, int mstrip0, int n, 
 // o: the 8 output values of one row as STORED (rounded to 16 bit); xr: the primal row chunk (modes 2, 3)
 template <int FL>
 __device__ __forceinline__ void gs_add(const GnStat& g, const GsCtx<FL>& c, const float* o, const uint4& xr, GsAcc& a) {
-  float x[8];
-  if (g.mode >= 2) H16<FL>::load8(reinterpret_cast<const bf16*>(&xr), x);
+  float t1[8], t2[8];
+  if (g.mode == 1) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int hi = e >= c.split ? 1 : 0;
-    float t1, t2;
-    if (g.mode == 1) { t1 = o[e]; t2 = o[e] * o[e]; }
-    else {
-      const float xh = (x[e] - c.mean[hi]) * c.rstd[hi];
+    for (int e = 0; e < 8; ++e) { t1[e] = o[e]; t2[e] = o[e] * o[e]; }
+  } else {
+    float x[8];
+    H16<FL>::load8(reinterpret_cast<const bf16*>(&xr), x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool hi = e >= c.split;
+      const float xh = (x[e] - (hi ? c.mean1 : c.mean0)) * (hi ? c.rstd1 : c.rstd0);
       float v = o[e];
       if (g.mode == 3) {
         const float y = c.gam[e] * xh + c.bet[e];
         v *= c.gam[e] * (g.silu ? dsilu_(y) : 1.f);
       }
-      t1 = v; t2 = xh * v;
+      t1[e] = v; t2[e] = xh * v;
     }
-    if (hi) { a.s[2] += t1; a.s[3] += t2; } else { a.s[0] += t1; a.s[1] += t2; }
   }
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool hi = e >= c.split;
+    a0 += hi ? 0.f : t1[e]; a1 += hi ? 0.f : t2[e];
+    b0 += hi ? t1[e] : 0.f; b1 += hi ? t2[e] : 0.f;
+  }
+  a.s0 += a0; a.s1 += a1; a.s2 += b0; a.s3 += b1;
 }
 // after the last slab of the wave's strip: fold the RPI lanes of each column, lane r0 = 0 stores.  rb_idx = strip index (mstrip0 / strip rows)
 template <int WN>
 __device__ __forceinline__ void gs_finish(const GemmArgs& p, GsAcc& a, int lane, int wave, long rb_idx, int n0) {
   constexpr int CPR = WN / 8;
   const int c8 = lane % CPR, n = n0 + (wave & 1) * WN + c8 * 8;
+  float v0 = a.s0, v1 = a.s1, v2 = a.s2, v3 = a.s3;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float v = a.s[q];
-#pragma unroll
-    for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-    a.s[q] = v;
+  for (int o = CPR; o < 64; o <<= 1) {
+    v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); v3 += __shfl_xor(v3, o, 64);
   }
   if (lane < CPR && n + 8 <= p.N)
-    *reinterpret_cast<float4*>(p.gs.part + (rb_idx * (p.N >> 3) + (n >> 3)) * 4) = make_float4(a.s[0], a.s[1], a.s[2], a.s[3]);
+    *reinterpret_cast<float4*>(p.gs.part + (rb_idx * (p.N >> 3) + (n >> 3)) * 4) = make_float4(v0, v1, v2, v3);
 }
 
-template <int FL, int WN, int SLD, int EPI>
+// GS (compile time): this instantiation emits GnStat -- kept out of the default kernels, where the mere presence of the statistics code (a run-time
+// branch) cost the 128 x 128 ring 10 % (registers / code size: 8.61 -> 8.82 ms per iteration, profiles/r04_gn_epi_stats.txt)
+template <int FL, int WN, int SLD, int EPI, int GS = 0>
 __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0, int n0,
                                      long slab_idx, GsAcc* gsa = nullptr, const GsCtx<FL>* gsc = nullptr) {
   constexpr int CPR = WN / 8;
   const int wx = wave & 1;
   const float* stage = smem_f + wave * 32 * SLD;
+  if constexpr (EPI == EPI_GEGLU_FWD) {
+    // forward pass (dpb_forward): y = a * gelu(g) straight from the FF-in product -- h [M][2F] is never written.  a and g are rounded to 16 bit first
+    // and the expression is the primal GEGLU kernel's (elementwise.hip), so the result is bitwise what product + geglu_kernel give.
+    const int F2 = p.N;
+    constexpr int NIT = WN == 64 ? 2 : 4;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int item = it * 64 + lane;
+      int row, c8, n, ncol;
+      const float *pa, *pg;
+      if constexpr (WN == 64) {                              // the wave pair (wx = 0, 1) holds a | g of the same 64 hidden units: 16 of the 32 rows each
+        const float* sa = smem_f + (wave & ~1) * 32 * SLD;
+        row = wx * 16 + item / CPR; c8 = item % CPR;
+        n = n0 + c8 * 8; ncol = (n0 >> 1) + c8 * 8;
+        pa = sa + row * SLD + c8 * 8; pg = sa + 32 * SLD + row * SLD + c8 * 8;
+      } else {                                               // 256 x 256 tile: the wave's own 128 columns are a | g of 64 hidden units
+        row = item >> 3; c8 = item & 7;
+        n = n0 + wx * WN + c8 * 8; ncol = ((n0 + wx * WN) >> 1) + c8 * 8;
+        pa = stage + row * SLD + c8 * 8; pg = pa + 64;
+      }
+      const int m = mrow0 + row;
+      if (m >= p.M || n >= p.N) continue;
+      float a8[8], g8[8], o[8];
+      Vec<float>::load(pa, a8); Vec<float>::load(pa + 4, a8 + 4);
+      Vec<float>::load(pg, g8); Vec<float>::load(pg + 4, g8 + 4);
+      if (p.bias) {
+        float b8[8];
+        Vec<float>::load(p.bias + n, b8); Vec<float>::load(p.bias + n + 4, b8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[e] = p.alpha * a8[e] + b8[e];
+        Vec<float>::load(p.bias + n + 64, b8); Vec<float>::load(p.bias + n + 68, b8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g8[e] = p.alpha * g8[e] + b8[e];
+      }
+      const bf16x8 ar = H16<FL>::pack8(a8), gr = H16<FL>::pack8(g8);     // the 16-bit h the unfused path stores and reloads
+      H16<FL>::load8(reinterpret_cast<const bf16*>(&ar), a8);
+      H16<FL>::load8(reinterpret_cast<const bf16*>(&gr), g8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float er = erff(g8[e] * 0.70710678118654752f);
+        const float g1 = 0.5f * g8[e] * (1.f + er);
+        o[e] = a8[e] * g1;
+      }
+      H16<FL>::store8(C + (long)m * p.ldc + ncol, o);
+    }
+    (void)F2;
+    return;
+  }
   if constexpr (EPI == EPI_GEGLU_TAN) {
     if constexpr (WN == 64) {
       const float* sa = smem_f + (wave & ~1) * 32 * SLD;      // a-half staged by wave wx = 0, g-half by its sibling wx = 1
@@ -311,7 +369,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
       Vec<float>::load(p.bias + n + 4, b8 + 4);
     }
     constexpr int BT = ITEMS > 4 ? 4 : ITEMS;
-    const bool gs_on = EPI == EPI_PLAIN && gsa && p.gs.mode;     // uniform over the launch
+    constexpr bool gs_on = EPI == EPI_PLAIN && GS != 0;
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += BT) {
       uint4 rr[BT], ro[BT], rb[BT], rx[BT];
@@ -321,7 +379,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
         if (R) rr[u] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + n);
         if (p.accumulate) ro[u] = *reinterpret_cast<const uint4*>(C + (long)mc * p.ldc + n);
         if (p.rowbias) rb[u] = *reinterpret_cast<const uint4*>((const bf16*)p.rowbias + (long)((mc / p.rows_per_sample) / p.rowbias_div) * p.N + n);
-        if (gs_on && p.gs.mode >= 2) rx[u] = *reinterpret_cast<const uint4*>(gsc->xrow + (long)(mc % p.gs.HW) * p.N);   // primal row of the statistics
+        if constexpr (gs_on) { if (p.gs.mode >= 2) rx[u] = *reinterpret_cast<const uint4*>(gsc->xrow + (long)(mc % p.gs.HW) * p.N); }   // primal row of the statistics
       }
 #pragma unroll
       for (int u = 0; u < BT; ++u) {
@@ -351,7 +409,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t8[e];
         }
-        if (gs_on) {                                 // statistics of the values as stored (what the consumer GroupNorm reads back)
+        if constexpr (gs_on) {                       // statistics of the values as stored (what the consumer GroupNorm reads back)
           const bf16x8 pk = H16<FL>::pack8(v);
           *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = pk;
           H16<FL>::load8(reinterpret_cast<const bf16*>(&pk), t8);

@@ -667,17 +667,8 @@ int gemm_gs_rows(int dtype, const GemmArgs& a, const GemmPlan& pl) {
   if (!a.gs.mode || !a.gs.part || dtype == DT_F32 || pl.splitk > 1 || a.epi != EPI_PLAIN || a.Z1 * a.Z2 != 1 || (a.N & 7) || a.ldc != a.N || a.A2) return 0;
   if (a.gs.cpg < 8 || a.gs.HW <= 0 || a.M % a.gs.HW) return 0;
   int rb = 0;
-  if (pl.kind == PLAN_HALO) rb = 64;
-  else if (pl.kind == PLAN_RING) {
-    switch (pl.tile) {
-      case 512: case 514: case 515: case 516: case 517: case 518: rb = 64; break;   // BK = 64 ring: 128x128 (4 waves), 256x128 / 256x256 (8 waves)
-      case 513: rb = 128; break;                                                     // 256x128, 4 waves
-      case 128: case 130: case 132: rb = 64; break;                                  // BK = 32 ring 128x128
-      case 256: rb = 128; break;
-      case 64: case 66: rb = 32; break;
-      default: rb = 0;
-    }
-  }
+  if (pl.kind == PLAN_HALO) rb = 64;                                  // conv_halo_kernel<.., GS = 1>: 64-row wave strips
+  else if (pl.kind == PLAN_RING && pl.tile == 515 && a.gather == GATHER_NONE) rb = 64;   // gemm_ring64_kernel<128,128,2,NONE,4,FL,PLAIN,GS = 1>
   if (!rb || a.gs.HW % rb) return 0;             // a strip must lie inside one sample / tangent
   return rb;
 }

@@ -225,9 +225,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
 
   // ---- epilogue through LDS (same scheme as gemm_kernel)
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
-  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat, epilogue.h): plain epilogue, unsplit launches only
-  const bool gs_on = EPI == EPI_PLAIN && p.gs.mode && p.splitk <= 1;
-  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_begin<FL>(p, m0 + wy * WM, min(n0 + wx * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc); }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -236,10 +233,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
     epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0,
-                               (long)blockIdx.z * gridDim.y + blockIdx.y, gs_on ? &gsa : nullptr, &gsc);
+                               (long)blockIdx.z * gridDim.y + blockIdx.y);
     __syncthreads();
   }
-  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * WM) / WM, n0); }
 }
 
 template <int BM, int BN, int S, int FL>
@@ -248,6 +244,7 @@ static void launch_dma_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
     case GATHER_NONE:
       if (a.epi == EPI_GEGLU_TAN) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL, EPI_GEGLU_TAN>), grid, dim3(256), 0, st, a);
       else if (a.epi == EPI_GEGLU_ADJ) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL, EPI_GEGLU_ADJ>), grid, dim3(256), 0, st, a);
+      else if (a.epi == EPI_GEGLU_FWD) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL, EPI_GEGLU_FWD>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_NONE, FL>), grid, dim3(256), 0, st, a);
       break;
     case GATHER_CONV: hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, S, GATHER_CONV, FL>), grid, dim3(256), 0, st, a); break;

@@ -69,7 +69,7 @@ __device__ inline void wait_dma(int stages_in_flight) {   // s_waitcnt vmcnt(sta
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0, int EPI = EPI_PLAIN>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; EPI: epilogue.h
+template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0, int EPI = EPI_PLAIN, int GS = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; EPI: epilogue.h; GS: emits GnStat
 __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   constexpr int BK = 64, CH = 8, KK = BK / 16;
   constexpr int NIA = BM / (8 * WAVES), NIB = BN / (8 * WAVES), U = NIA + NIB;   // DMA wave-instructions (8 rows each) per stage per wave
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   };
 
   GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat): plain epilogue, unsplit launches; constants fetched here, under the K loop
-  const bool gs_on = EPI == EPI_PLAIN && p.gs.mode && p.splitk <= 1;
-  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_begin<FL>(p, m0 + (wave >> 1) * WM, min(n0 + (wave & 1) * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc); }
+  constexpr bool gs_on = EPI == EPI_PLAIN && GS != 0;
+  if constexpr (gs_on) gs_begin<FL>(p, m0 + (wave >> 1) * WM, min(n0 + (wave & 1) * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc);
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -300,12 +300,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
       // staged rows: wave pair wy holds tile rows wy*WM + i*32 .. +31; epilogue_ln's row index wy*32 + row maps to tile row wy*WM + i*32 + row
       epilogue_ln<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + i * 32 + (wave >> 1) * (WM - 32), lnq[i]);
     } else {
-      epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb,
-                                       gs_on ? &gsa : nullptr, &gsc);
+      epilogue_slab<FL, WN, SLD, EPI, GS>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb,
+                                           &gsa, &gsc);
     }
     __syncthreads();
   });
-  if constexpr (EPI == EPI_PLAIN) { if (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * WM) / WM, n0); }
+  if constexpr (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * WM) / WM, n0);
 }
 
 template <int BM, int BN, int S, int WAVES, int FL>
@@ -315,6 +315,7 @@ static void launch_ring64_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
       if constexpr (BN == 128) {                  // the fused GEGLU epilogues pair the two 64-column waves of a 128-column tile
         if (a.epi == EPI_GEGLU_TAN) { hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_TAN>), grid, dim3(WAVES * 64), 0, st, a); break; }
         if (a.epi == EPI_GEGLU_ADJ) { hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_ADJ>), grid, dim3(WAVES * 64), 0, st, a); break; }
+        if (a.epi == EPI_GEGLU_FWD) { hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL, EPI_GEGLU_FWD>), grid, dim3(WAVES * 64), 0, st, a); break; }
       }
       hipLaunchKernelGGL((gemm_ring64_kernel<BM, BN, S, GATHER_NONE, WAVES, FL>), grid, dim3(WAVES * 64), 0, st, a);
       break;
@@ -349,6 +350,7 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
 #define DPB_RING518(FLV, EPIV) hipLaunchKernelGGL((gemm_ring64_kernel<256, 256, 2, GATHER_NONE, 8, FLV, EPIV>), g, dim3(512), 0, st, a)
     if (a.epi == EPI_GEGLU_TAN) { if (a.fl) DPB_RING518(1, EPI_GEGLU_TAN); else DPB_RING518(0, EPI_GEGLU_TAN); }
     else if (a.epi == EPI_GEGLU_ADJ) { if (a.fl) DPB_RING518(1, EPI_GEGLU_ADJ); else DPB_RING518(0, EPI_GEGLU_ADJ); }
+    else if (a.epi == EPI_GEGLU_FWD) { if (a.fl) DPB_RING518(1, EPI_GEGLU_FWD); else DPB_RING518(0, EPI_GEGLU_FWD); }
     else { if (a.fl) DPB_RING518(1, EPI_PLAIN); else DPB_RING518(0, EPI_PLAIN); }
 #undef DPB_RING518
   }
@@ -361,6 +363,11 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
 #undef DPB_RING520
   }
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
+  else if (tile == 515 && a.gs.mode) {          // the statistics-emitting instantiation: plain rows, plain epilogue, unsplit (gemm_gs_rows)
+    const dim3 g = tiles(128, 128);
+    if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<128, 128, 2, GATHER_NONE, 4, 1, EPI_PLAIN, 1>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_ring64_kernel<128, 128, 2, GATHER_NONE, 4, 0, EPI_PLAIN, 1>), g, dim3(256), 0, st, a);
+  }
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);
   else launch_ring64_t<128, 128, 3>(a, tiles(128, 128), st);
   DPB_CHECK(hipGetLastError());

@@ -10,7 +10,7 @@ namespace dpb {
 // C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k]  (+bias[n]) (+rowbias[sample(m)][n]) (+R[z][m][n]) (+C if accumulate)
 // A: plain rows (lda) or gathered NHWC pixels (conv).  B is always [N][K], K contiguous.
 enum { GATHER_NONE = 0, GATHER_CONV = 1, GATHER_CONVT = 2, GATHER_UPCONV = 3 };
-enum { EPI_PLAIN = 0, EPI_GEGLU_TAN = 1, EPI_GEGLU_ADJ = 2, EPI_LN_TAN = 3, EPI_LN_ADJ = 4 };   // fused epilogues of the ring GEMMs (epilogue.h)
+enum { EPI_PLAIN = 0, EPI_GEGLU_TAN = 1, EPI_GEGLU_ADJ = 2, EPI_LN_TAN = 3, EPI_LN_ADJ = 4, EPI_GEGLU_FWD = 5 };   // fused epilogues of the ring GEMMs (epilogue.h)
 // GroupNorm statistics of a product's OUTPUT tensor, emitted by the product's own epilogue (epilogue.h, gs_*): the consumer GroupNorm then needs no
 // statistics launch.  One partial per (row block of `rb` rows = the wave's row strip, 16-byte chunk column): float4 (s1, s2 of the chunk's channels in
 // its first group, s1, s2 of those in its second group) -- a chunk of 8 channels spans at most two groups (cpg >= 8); plain stores, fixed order, and the
