@@ -180,9 +180,9 @@ struct FusedArgs {
 // O = softmax(scale Q K^T) V with online softmax; also emits the row statistics (m, 1/l) the tangent / adjoint
 // kernels need, so the L x L probabilities are never materialised for the fused layers.  Same tiling as below:
 // lane <-> query, so the running max / sum and the rescale of the accumulator are register-local.
-template <int D, int FL>
-__global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
-  using F = FA<D>;
+template <int D, int FL, int W = att_waves(D)>   // W waves (32 query rows each) per block
+__global__ __launch_bounds__((FA<D, W>::NT)) void attn_fwd_kernel(FusedArgs a, bf16* O, float* stats_out) {
+  using F = FA<D, W>;
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * F::ROW_ELEMS];
   bf16* sK = sm; bf16* sV = sK + F::ROW_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -203,15 +203,15 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_fwd_kernel(FusedArgs a, bf16* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  RowRegs<D> rK, rV;
-  fetch_row<D>(Kp, a.C, rK, tid); fetch_row<D>(Vp, a.C, rV, tid);
+  RowRegs<D, F::NT> rK, rV;
+  fetch_row<D, F::NT>(Kp, a.C, rK, tid); fetch_row<D, F::NT>(Vp, a.C, rV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();
-    commit_row<D>(rK, sK, tid); commit_row<D>(rV, sV, tid);
+    commit_row<D, F::NT>(rK, sK, tid); commit_row<D, F::NT>(rV, sV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {
       const int k1 = k0 + F::BI;
-      fetch_row<D>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D>(Vp + (long)k1 * a.C, a.C, rV, tid);
+      fetch_row<D, F::NT>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, F::NT>(Vp + (long)k1 * a.C, a.C, rV, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < F::BI / 32; ++kb) {
@@ -1224,6 +1224,17 @@ int launch_attn_fwd_fused(const FusedAttnArgs& f, int batch, void* O, float* sta
   FusedArgs a = to_args(f);
   dim3 grid((f.L + att_waves(f.d) * 32 - 1) / (att_waves(f.d) * 32), batch * f.H);
   if (!head_dim_ok(f.d)) { set_error("fused attention: head dim %d unsupported", f.d); return -1; }
+  // one sample at the 64x64 / 32x32 levels: 8-wave blocks of 256 queries leave half (or more) of the 256 CUs without a block (16 x 8 heads = 128
+  // blocks at L = 4096) -- 4-wave blocks of 128 queries then (the DDIM inversion / forward-to-edit_t steps and the primal pass of a pullback run at batch 1)
+  static const int fwd4 = getenv("DPB_ATTN_FWD4") ? atoi(getenv("DPB_ATTN_FWD4")) : 1;   // tuning switch
+  if (fwd4 && att_waves(f.d) == 8 && f.L % 128 == 0 && f.L >= 256 && (long)grid.x * grid.y < 256) {
+    dim3 g4(f.L / 128, batch * f.H);
+    if (f.d == 40) { if (f.fl) hipLaunchKernelGGL((attn_fwd_kernel<40, 1, 4>), g4, dim3(256), 0, st, a, (bf16*)O, stats); else hipLaunchKernelGGL((attn_fwd_kernel<40, 0, 4>), g4, dim3(256), 0, st, a, (bf16*)O, stats); }
+    else if (f.d == 64) { if (f.fl) hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 4>), g4, dim3(256), 0, st, a, (bf16*)O, stats); else hipLaunchKernelGGL((attn_fwd_kernel<64, 0, 4>), g4, dim3(256), 0, st, a, (bf16*)O, stats); }
+    else { if (f.fl) hipLaunchKernelGGL((attn_fwd_kernel<80, 1, 4>), g4, dim3(256), 0, st, a, (bf16*)O, stats); else hipLaunchKernelGGL((attn_fwd_kernel<80, 0, 4>), g4, dim3(256), 0, st, a, (bf16*)O, stats); }
+    DPB_CHECK(hipGetLastError());
+    return 0;
+  }
   DPB_ATT_DISPATCH(f.d, f.fl, hipLaunchKernelGGL((attn_fwd_kernel<D, FL>), grid, dim3(att_waves(D) * 64), 0, st, a, (bf16*)O, stats));
   DPB_CHECK(hipGetLastError());
   return 0;

@@ -61,8 +61,6 @@ struct Op {
   int geglu_prev = -1;       // CONV (FF-out): the GEGLU op that produces its input                                   -> fused adjoint epilogue
   int ln_next = -1;          // CONV: the LayerNorm op that reads its 320-wide output  -> tangent: product + LayerNorm tangent in one launch (EPI_LN_TAN)
   int ln_prev = -1;          // CONV: the LayerNorm op whose output is its only input -> adjoint: product + LayerNorm adjoint in one launch (EPI_LN_ADJ)
-  int gn_next = -1;          // CONV: a GroupNorm op reading its output          -> primal / tangent: the product's epilogue emits that op's statistics (GnStat)
-  int gn_prev = -1;          // CONV: the GroupNorm op whose output is its only input -> adjoint: the adjoint product's epilogue emits the statistics of the GroupNorm adjoint
 };
 
 }  // namespace dpb
@@ -85,8 +83,6 @@ struct dpb_engine {
   size_t S1 = 0, S2 = 0, T1 = 0, Dv = 0, convtmp = 0, io_in = 0, io_out = 0, orth = 0, slab = 0, slab_bytes = 64u << 20, zeros = 0;
   size_t orth_stride = 0;                  // re-orthonormalisation scratch per sample of the batch
   size_t pbW = 0;                          // pullback loop fp32 staging of W = J^T J V
-  size_t gspart = 0, gspart_bytes = 0;     // GroupNorm statistics partials written by the producing product's epilogue (GnStat)
-  int gs_buf = -1, gs_mode = 0, gs_rb = 0; // what the partials in gspart describe: buffer, GnStat mode, rows per partial block (0: nothing valid)
   size_t temb_host_stage = 0;
   int cur_batch = 0;
   std::vector<int> uses;            // buffer -> number of ops reading it (in0 / in1 / in2 / res)
@@ -165,26 +161,7 @@ void prof_close(dpb_engine* e, int idx) {
 int g_geglu_fwd = getenv("DPB_GEGLU_FWD") ? atoi(getenv("DPB_GEGLU_FWD")) : 1;
 // one-launch forward of the text-conditioned attention layers (A/B switch: DPB_CROSS_PRIMAL=0, dpb_debug_set("cross_primal", 0): the materialised path)
 int g_cross_primal = getenv("DPB_CROSS_PRIMAL") ? atoi(getenv("DPB_CROSS_PRIMAL")) : 1;
-// GroupNorm statistics from the producer's epilogue (A/B switch: DPB_GN_EPI_STATS=0, dpb_debug_set("gn_epi_stats", 0): every two-pass GroupNorm runs its own statistics launch)
-int g_gn_epi_stats = getenv("DPB_GN_EPI_STATS") ? atoi(getenv("DPB_GN_EPI_STATS")) : 1;
-
-// ask the product `g` (whose output rows are the input of GroupNorm op `gn` in pass `mode`) for that op's statistics; n = samples / tangents in the pass
-void gs_request(dpb_engine* e, GemmArgs& g, const Op& gn, int mode, int n) {
-  const dpb_op_desc& d = gn.d;
-  const Buf& bi = e->bufs[d.in0];
-  if (!g_gn_epi_stats || e->dtype == DT_F32 || !gn_deterministic() || !e->gspart_bytes || gn.is_const) return;
-  GNArgs probe; probe.HW = bi.rows; probe.C = bi.C; probe.G = d.ip[0]; probe.NT = n; probe.Bp = n;
-  if (groupnorm_launches(e->dtype, mode, probe) < 2) return;              // small maps: the one-launch kernel needs no statistics from anyone
-  if ((size_t)((long)n * bi.rows / 32 + 1) * (bi.C / 8) * 16 > e->gspart_bytes) return;
-  g.gs.part = (float*)(e->ws + e->gspart);
-  g.gs.mode = mode == MODE_PRIMAL ? 1 : mode == MODE_TANGENT ? 2 : 3;
-  g.gs.cpg = bi.C / d.ip[0]; g.gs.G = d.ip[0]; g.gs.HW = bi.rows; g.gs.silu = d.ip[1];
-  g.gs.kps = mode == MODE_PRIMAL ? 1 : n / e->cur_batch;
-  g.gs.x = e->P(d.in0); g.gs.pstats = (const double*)(e->ws + gn.pstats);
-  g.gs.gamma = (const float*)d.w[0]; g.gs.beta = (const float*)d.w[1];
-}
-
-int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false, int gs_buf = -1) {
+int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false) {
   // a product parked by an EARLIER gemm() of the same op (run_op has flushed everything older) must be reduced before this one reuses the slabs
   if (e->pend.on)
     if (int r = flush_pending(e)) return r;
@@ -194,9 +171,7 @@ int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false, int gs_buf = -1) {
   e->flops += 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
   int nl = 1;                                   // kernels enqueued: the product itself (+ splitk_reduce_kernel for split-K launches)
-  int gs_rb = 0;
-  auto gs_note = [&]() { if (a.gs.mode) { e->gs_rb = gs_rb; e->gs_buf = gs_buf; e->gs_mode = a.gs.mode; } };   // (a product without a request leaves earlier partials alone)
-  if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl, pend, &gs_rb); e->n_launch += nl; e->pend.on = pend && pend->splitk > 1; gs_note(); return r; }
+  if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl, pend); e->n_launch += nl; e->pend.on = pend && pend->splitk > 1; return r; }
   dpb_engine::Prof p;
   p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
   { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile
@@ -204,10 +179,9 @@ int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false, int gs_buf = -1) {
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));
   DPB_CHECK(hipEventRecord(p.a, e->stream));
-  int r = launch_gemm(e->dtype, a, e->stream, &nl, pend, &gs_rb);
+  int r = launch_gemm(e->dtype, a, e->stream, &nl, pend);
   e->n_launch += nl;
   e->pend.on = pend && pend->splitk > 1;
-  gs_note();
   DPB_CHECK(hipEventRecord(p.b, e->stream));
   e->prof.push_back(p);
   return r;
@@ -292,8 +266,7 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
   // tangent: a following one-launch GroupNorm / LayerNorm may add the split-K slabs itself.  (Primal / forward-only products too were tried in
   // round 3 -- bias and time-embedding row added by the consumer: 599 -> 573 launches per B = 2 forward but 7.47 -> 7.55 ms: the slabs are 16x
   // the bytes of the 16-bit tensor and the primal consumers have nothing to hide them under.)
-  if (op.gn_next >= 0 && !shared_out) gs_request(e, g, e->ops[op.gn_next], mode == 0 ? MODE_PRIMAL : MODE_TANGENT, n);
-  return gemm(e, g, mode == 1 && !shared_out, d.out);
+  return gemm(e, g, mode == 1 && !shared_out);
 }
 
 int conv_adj(dpb_engine* e, const Op& op, int n) {
@@ -343,22 +316,18 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
       }
     }
     const bool lone = e->uses[d.in0] == 1 && d.in0 != e->x_buf;   // the cotangent has this one contribution: its producer's adjoint may add the slabs
-    // the GroupNorm that wrote this product's input: the statistics of its adjoint (of v = gamma silu'(y) gz, gz = this product) leave the epilogue
-    const bool gs = op.gn_prev >= 0 && lone && !e->ginit[d.in0];
     if (gather == GATHER_NONE) {
       g.M = n * bi.rows;
       g.C = e->G(d.in0);
       g.accumulate = e->ginit[d.in0];
-      if (gs) gs_request(e, g, e->ops[op.gn_prev], MODE_ADJOINT, n);
-      if (int r = gemm(e, g, lone, d.in0)) return r;
+      if (int r = gemm(e, g, lone)) return r;
     } else if (gather == GATHER_CONV) {
       g.gather = GATHER_CONVT;
       g.M = n * H * W;
       g.H = Ho; g.W = Wo; g.Cin = Cout; g.Ho = H; g.Wo = W; g.KS = KS; g.stride = d.ip[7]; g.pad = d.ip[8];
       g.C = e->G(d.in0);
       g.accumulate = e->ginit[d.in0];
-      if (gs) gs_request(e, g, e->ops[op.gn_prev], MODE_ADJOINT, n);
-      if (int r = gemm(e, g, lone, d.in0)) return r;
+      if (int r = gemm(e, g, lone)) return r;
     } else {   // UPCONV: adjoint conv at the upsampled resolution, then 2x2 sum pooling
       g.gather = GATHER_CONVT;
       g.M = n * Ho * Wo;
@@ -442,12 +411,6 @@ int gn_run(dpb_engine* e, const Op& op, int mode, int n) {
     }
     take_pending(e, a.src, a.d, mode == MODE_TANGENT && (e->uses[d.in0] > 1 || d.in0 == e->cur_tap));
   }
-  // statistics left by the epilogue of the product that wrote this op's input (tangent / primal) or the cotangent of its output (adjoint)
-  if (e->gs_rb && e->gs_buf == (mode == MODE_ADJOINT ? d.out : d.in0) && e->gs_mode == (mode == MODE_PRIMAL ? 1 : mode == MODE_TANGENT ? 2 : 3)) {
-    a.ppart = (const float*)(e->ws + e->gspart);
-    a.prb = e->gs_rb;
-  }
-  e->gs_rb = 0;
   e->n_launch += groupnorm_launches(e->dtype, mode, a);
   return launch_groupnorm(e->dtype, mode, a, e->stream);
 }
@@ -931,19 +894,6 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
         if (cd.kind == DPB_OP_CONV && cd.ip[9] == DPB_GATHER_NONE && cd.in0 == d.out) e->ops[ci].geglu_prev = (int)j;
       }
     }
-    // GroupNorm statistics from the producing product's epilogue: the conv that writes a GroupNorm's input (primal / tangent), the conv that is the
-    // only reader of a GroupNorm's output (its adjoint writes the cotangent the GroupNorm adjoint reads)
-    for (size_t j = 0; j < e->ops.size(); ++j) {
-      const dpb_op_desc& d = e->ops[j].d;
-      if (d.kind != DPB_OP_GROUPNORM || e->bufs[d.in0].kind != DPB_BUF_ACT) continue;
-      const int pi = e->producer[d.in0];
-      if (pi >= 0 && e->ops[pi].d.kind == DPB_OP_CONV && e->ops[pi].gn_next < 0) e->ops[pi].gn_next = (int)j;
-      if (uses[d.out] == 1) {
-        const int ci = user[d.out];
-        const dpb_op_desc& cd = e->ops[ci].d;
-        if (cd.kind == DPB_OP_CONV && cd.in0 == d.out) e->ops[ci].gn_prev = (int)j;
-      }
-    }
     e->skip.assign(e->ops.size(), 0);
   }
   // ---------------- memory plan
@@ -1021,16 +971,6 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   e->zeros = take(256);
   const size_t nx = (size_t)e->bufs[e->x_buf].rows * e->x_channels;
   e->pbW = take((size_t)e->maxT * nx * sizeof(float));
-  {  // GnStat partials: one float4 per (32-row block, 16-byte chunk column) of the largest GroupNorm input
-    size_t need = 0;
-    for (auto& op : e->ops)
-      if (op.d.kind == DPB_OP_GROUPNORM) {
-        const Buf& b = e->bufs[op.d.in0];
-        need = std::max(need, ((size_t)std::max(e->maxB, e->maxT) * b.rows / 32 + 1) * (b.C / 8) * 16);
-      }
-    e->gspart_bytes = e->dtype == DT_F32 ? 0 : need;
-    e->gspart = take(e->gspart_bytes);
-  }
   e->ws_bytes = off;
   e->ginit.assign(nb, 0);
   *out = e;
@@ -1097,7 +1037,7 @@ static int primal_pass(dpb_engine* e, const float* x, int batch, float t, const 
   }
   if (e->pstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->pstats_off, 0, e->pstats_bytes, e->stream));   // atomic statistics path accumulates
   e->cur_batch = batch;
-  e->cur_tap = upto_buf; e->pend.on = false; e->gs_rb = 0;
+  e->cur_tap = upto_buf; e->pend.on = false;
   const int last = e->producer[upto_buf];
   std::fill(e->skip.begin(), e->skip.end(), 0);
   for (int i = 0; i <= last; ++i) {
@@ -1142,7 +1082,7 @@ int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
   if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));   // atomic statistics accumulate
   const int last = e->producer[tap];
   std::fill(e->skip.begin(), e->skip.end(), 0);
-  e->cur_tap = tap; e->pend.on = false; e->gs_rb = 0;
+  e->cur_tap = tap; e->pend.on = false;
   for (int i = 0; i <= last; ++i) {
     if (e->ops[i].is_const || e->skip[i]) continue;
     if (int r = run_op(e, e->ops[i], MODE_TANGENT, nt)) return r;
@@ -1164,7 +1104,7 @@ int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
   e->ginit[tap] = 1;
   if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
-  e->cur_tap = tap; e->pend.on = false; e->gs_rb = 0;
+  e->cur_tap = tap; e->pend.on = false;
   for (int i = e->producer[tap]; i >= 0; --i) {
     const Op& op = e->ops[i];
     if (op.is_const || !e->ginit[op.d.out]) continue;
@@ -1353,7 +1293,6 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "attn_shared")) { attn_debug_shared(value); return 0; }
   else if (!strcmp(key, "lazy_reduce")) { g_lazy_reduce = value; return 0; }
   else if (!strcmp(key, "ln_fuse")) { g_ln_fuse = value; return 0; }
-  else if (!strcmp(key, "gn_epi_stats")) { g_gn_epi_stats = value; return 0; }
   else if (!strcmp(key, "cross_primal")) { g_cross_primal = value; return 0; }
   else if (!strcmp(key, "geglu_fwd")) { g_geglu_fwd = value; return 0; }
   else return fail("unknown debug key %s", key);

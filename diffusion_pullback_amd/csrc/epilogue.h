@@ -125,85 +125,12 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& p, bf16* C, const bf
   }
 }
 
-// ---- GroupNorm statistics of the output, from the epilogue (GnStat, kernels.h).  A lane keeps its 16-byte column across the items and slabs of its
-// wave's row strip, so it sums its rows in registers (GsAcc), the RPI lanes of a column are folded by a fixed xor tree, and ONE lane per column stores
-// the strip's float4 partial: no atomics, no LDS, the same additions in the same order every run.
-struct GsAcc { float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f; };    // scalars, not an array: a dynamically indexed register array is demoted to scratch
-template <int FL>
-struct GsCtx {                       // per-lane constants of the statistics (filled once per wave strip: gs_begin)
-  int split = 8;                     // elements e >= split of the chunk belong to the chunk's second group
-  float mean0 = 0.f, mean1 = 0.f, rstd0 = 0.f, rstd1 = 0.f;
-  float gam[8], bet[8];
-  const bf16* xrow = nullptr;        // primal rows of this strip's sample: x + (sample * HW) * N + n
-};
-template <int FL>
-__device__ __forceinline__ void gs_begin(const GemmArgs& p, int mstrip0, int n, GsCtx<FL>& c) {
-  const GnStat& g = p.gs;
-  const int g0 = n / g.cpg;
-  c.split = (g0 + 1) * g.cpg - n;
-  if (g.mode >= 2) {
-    const int mm = min(mstrip0, p.M - 1);
-    const int smp = (mm / g.HW) / g.kps;                       // the whole strip lies in one tangent / cotangent (HW % strip rows == 0)
-    const int g1 = min(g0 + 1, g.G - 1);
-    c.mean0 = (float)g.pstats[((long)smp * g.G + g0) * 2]; c.rstd0 = (float)g.pstats[((long)smp * g.G + g0) * 2 + 1];
-    c.mean1 = (float)g.pstats[((long)smp * g.G + g1) * 2]; c.rstd1 = (float)g.pstats[((long)smp * g.G + g1) * 2 + 1];
-    c.xrow = (const bf16*)g.x + (long)smp * g.HW * p.N + n;
-    if (g.mode == 3) {
-      Vec<float>::load(g.gamma + n, c.gam); Vec<float>::load(g.gamma + n + 4, c.gam + 4);
-      Vec<float>::load(g.beta + n, c.bet); Vec<float>::load(g.beta + n + 4, c.bet + 4);
-    }
-  }
-}
-// o: the 8 output values of one row as STORED (rounded to 16 bit); xr: the primal row chunk (modes 2, 3)
-template <int FL>
-__device__ __forceinline__ void gs_add(const GnStat& g, const GsCtx<FL>& c, const float* o, const uint4& xr, GsAcc& a) {
-  float t1[8], t2[8];
-  if (g.mode == 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { t1[e] = o[e]; t2[e] = o[e] * o[e]; }
-  } else {
-    float x[8];
-    H16<FL>::load8(reinterpret_cast<const bf16*>(&xr), x);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool hi = e >= c.split;
-      const float xh = (x[e] - (hi ? c.mean1 : c.mean0)) * (hi ? c.rstd1 : c.rstd0);
-      float v = o[e];
-      if (g.mode == 3) {
-        const float y = c.gam[e] * xh + c.bet[e];
-        v *= c.gam[e] * (g.silu ? dsilu_(y) : 1.f);
-      }
-      t1[e] = v; t2[e] = xh * v;
-    }
-  }
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool hi = e >= c.split;
-    a0 += hi ? 0.f : t1[e]; a1 += hi ? 0.f : t2[e];
-    b0 += hi ? t1[e] : 0.f; b1 += hi ? t2[e] : 0.f;
-  }
-  a.s0 += a0; a.s1 += a1; a.s2 += b0; a.s3 += b1;
-}
-// after the last slab of the wave's strip: fold the RPI lanes of each column, lane r0 = 0 stores.  rb_idx = strip index (mstrip0 / strip rows)
-template <int WN>
-__device__ __forceinline__ void gs_finish(const GemmArgs& p, GsAcc& a, int lane, int wave, long rb_idx, int n0) {
-  constexpr int CPR = WN / 8;
-  const int c8 = lane % CPR, n = n0 + (wave & 1) * WN + c8 * 8;
-  float v0 = a.s0, v1 = a.s1, v2 = a.s2, v3 = a.s3;
-#pragma unroll
-  for (int o = CPR; o < 64; o <<= 1) {
-    v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); v3 += __shfl_xor(v3, o, 64);
-  }
-  if (lane < CPR && n + 8 <= p.N)
-    *reinterpret_cast<float4*>(p.gs.part + (rb_idx * (p.N >> 3) + (n >> 3)) * 4) = make_float4(v0, v1, v2, v3);
-}
-
-// GS (compile time): this instantiation emits GnStat -- kept out of the default kernels, where the mere presence of the statistics code (a run-time
-// branch) cost the 128 x 128 ring 10 % (registers / code size: 8.61 -> 8.82 ms per iteration, profiles/r04_gn_epi_stats.txt)
-template <int FL, int WN, int SLD, int EPI, int GS = 0>
+// (Round 4 built GroupNorm statistics of the output into this epilogue -- per-lane column sums, a fixed xor tree, one float4 per wave strip and
+// column -- so that the consumer GroupNorm needed no statistics launch: 335 -> 321 launches, 0.4-0.7 % SLOWER; the tangent / adjoint statistics
+// need the primal tensor next to the output, an extra read that lands in the one HBM-bound phase of the product.  profiles/r04_gn_epi_stats.txt.)
+template <int FL, int WN, int SLD, int EPI>
 __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0, int n0,
-                                     long slab_idx, GsAcc* gsa = nullptr, const GsCtx<FL>* gsc = nullptr) {
+                                     long slab_idx) {
   constexpr int CPR = WN / 8;
   const int wx = wave & 1;
   const float* stage = smem_f + wave * 32 * SLD;
@@ -369,17 +296,15 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
       Vec<float>::load(p.bias + n + 4, b8 + 4);
     }
     constexpr int BT = ITEMS > 4 ? 4 : ITEMS;
-    constexpr bool gs_on = EPI == EPI_PLAIN && GS != 0;
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += BT) {
-      uint4 rr[BT], ro[BT], rb[BT], rx[BT];
+      uint4 rr[BT], ro[BT], rb[BT];
 #pragma unroll
       for (int u = 0; u < BT; ++u) {
         const int mc = min(mrow0 + (it0 + u) * RPI + r0, p.M - 1);
         if (R) rr[u] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + n);
         if (p.accumulate) ro[u] = *reinterpret_cast<const uint4*>(C + (long)mc * p.ldc + n);
         if (p.rowbias) rb[u] = *reinterpret_cast<const uint4*>((const bf16*)p.rowbias + (long)((mc / p.rows_per_sample) / p.rowbias_div) * p.N + n);
-        if constexpr (gs_on) { if (p.gs.mode >= 2) rx[u] = *reinterpret_cast<const uint4*>(gsc->xrow + (long)(mc % p.gs.HW) * p.N); }   // primal row of the statistics
       }
 #pragma unroll
       for (int u = 0; u < BT; ++u) {
@@ -409,14 +334,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t8[e];
         }
-        if constexpr (gs_on) {                       // statistics of the values as stored (what the consumer GroupNorm reads back)
-          const bf16x8 pk = H16<FL>::pack8(v);
-          *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = pk;
-          H16<FL>::load8(reinterpret_cast<const bf16*>(&pk), t8);
-          gs_add<FL>(p.gs, *gsc, t8, rx[u], *gsa);
-        } else {
-          H16<FL>::store8(C + (long)m * p.ldc + n, v);
-        }
+        H16<FL>::store8(C + (long)m * p.ldc + n, v);
       }
     }
   } else {

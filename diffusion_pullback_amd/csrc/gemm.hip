@@ -447,7 +447,6 @@ void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_forc
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 static thread_local int t_reduce_launched = 0;   // set by launch_t when a splitk_reduce_kernel launch followed the product
 static thread_local GemmArgs* t_pending = nullptr;   // launch_gemm(..., pending): where a deferrable reduction is parked instead of launched
-static thread_local int t_gs_rb = 0;                 // rows per GnStat partial block the last launch emitted (0: none)
 
 int gemm_uses_big_tile(int dtype, const GemmArgs& a) {
   // Register-staged kernel, measured on MI355X (tools/gpu_gemm_bench.py, profiles/r01_gemm_microbench.txt):
@@ -662,17 +661,6 @@ GemmPlan gemm_plan(int dtype, const GemmArgs& a) {
   return pl;
 }
 
-// rows per statistics partial block (= the wave row strip of the planned kernel) if that kernel's epilogue can emit GnStat for this launch, else 0
-int gemm_gs_rows(int dtype, const GemmArgs& a, const GemmPlan& pl) {
-  if (!a.gs.mode || !a.gs.part || dtype == DT_F32 || pl.splitk > 1 || a.epi != EPI_PLAIN || a.Z1 * a.Z2 != 1 || (a.N & 7) || a.ldc != a.N || a.A2) return 0;
-  if (a.gs.cpg < 8 || a.gs.HW <= 0 || a.M % a.gs.HW) return 0;
-  int rb = 0;
-  if (pl.kind == PLAN_HALO) rb = 64;                                  // conv_halo_kernel<.., GS = 1>: 64-row wave strips
-  else if (pl.kind == PLAN_RING && pl.tile == 515 && a.gather == GATHER_NONE) rb = 64;   // gemm_ring64_kernel<128,128,2,NONE,4,FL,PLAIN,GS = 1>
-  if (!rb || a.gs.HW % rb) return 0;             // a strip must lie inside one sample / tangent
-  return rb;
-}
-
 template <typename T, int BM, int BN, int KCH>
 static void launch_reg_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   switch (a.gather) {
@@ -707,8 +695,6 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   const GemmPlan pl = gemm_plan(dtype, a);
   if (pl.kind < 0) return -1;
   a.splitk = pl.splitk;
-  t_gs_rb = a.vec_ok ? gemm_gs_rows(dtype, a, pl) : 0;
-  if (!t_gs_rb) a.gs.mode = 0;                      // this kernel / split cannot emit the statistics: the GroupNorm runs its own statistics launch
   if (pl.kind == PLAN_HALO) {
     if (int r = launch_conv_halo(a, st)) return r;
   } else if (pl.kind == PLAN_RING) {
@@ -745,11 +731,10 @@ int launch_gemm_reduce(int dtype, const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches, GemmArgs* pending, int* gs_rb) {
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches, GemmArgs* pending) {
   GemmArgs b = a;
   b.fl = dtype == DT_F16;           // 16-bit flavour of the specialised kernels (H16<fl>)
   t_reduce_launched = 0;
-  t_gs_rb = 0;
   if (pending) pending->splitk = 1;
   t_pending = pending;
   static const int trace = getenv("DPB_GEMM_TRACE") ? atoi(getenv("DPB_GEMM_TRACE")) : 0;   // debugging: print every product, synchronise after it
@@ -762,7 +747,6 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches, Gem
   if (trace && hipStreamSynchronize(st) != hipSuccess) fprintf(stderr, "gemm: the launch above failed\n");
   t_pending = nullptr;
   if (launches) *launches = 1 + t_reduce_launched;
-  if (gs_rb) *gs_rb = r ? 0 : t_gs_rb;
   return r;
 }
 

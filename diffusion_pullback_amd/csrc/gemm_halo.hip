@@ -47,7 +47,7 @@ constexpr int HALO_MAXPIX = 400;
 constexpr int HALO_BYTES = ((HALO_MAXPIX * 8 + 63) / 64) * 1024;        // whole wave instructions: 51,200 B
 constexpr int HALO_BSTAGE = HALO_BN * 128, HALO_S = 3;
 
-template <int GATHER, int FL = 0, int GS = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; GS: emits GnStat (epilogue.h)
+template <int GATHER, int FL = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16
 __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
   constexpr int BM = HALO_BM, BN = HALO_BN, WAVES = 8, NH = HALO_NH, S = HALO_S, KK = 4;
   constexpr int NIB = BN / (8 * WAVES);                                  // 2 weight DMA instructions per wave and stage
@@ -141,9 +141,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int wy = wave >> 1, wx = wave & 1, l31 = lane & 31, lhi = lane >> 5;
-  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat, epilogue.h): unsplit launches; constants fetched under the K loop
-  constexpr bool gs_on = GS != 0;
-  if constexpr (gs_on) gs_begin<FL>(p, m0 + wy * 64, min(n0 + wx * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc);
   int pixm[2];                                                            // halo pixel of the CENTRE tap for this lane's two A-fragment rows
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -229,10 +226,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    epilogue_slab<FL, WN, SLD, EPI_PLAIN, GS>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * 64 + i * 32, n0, (long)ksplit, &gsa, &gsc);
+    epilogue_slab<FL, WN, SLD, EPI_PLAIN>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * 64 + i * 32, n0, (long)ksplit);
     __syncthreads();
   }
-  if constexpr (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * 64) / 64, n0);
 }
 
 // 3x3, stride 1, pad 1, forward gather or its adjoint; whole image rows (or whole small images) per tile; 64-channel chunks
@@ -257,12 +253,10 @@ int launch_conv_halo(const GemmArgs& a, hipStream_t st) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   dim3 grid(((a.M + HALO_BM - 1) / HALO_BM) * ((a.N + HALO_BN - 1) / HALO_BN), 1, sk);
   if (a.gather == GATHER_CONV) {
-    if (a.gs.mode) { if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 1, 1>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 0, 1>), grid, dim3(512), 0, st, a); }
-    else if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 1>), grid, dim3(512), 0, st, a);
+    if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONV, 0>), grid, dim3(512), 0, st, a);
   } else {
-    if (a.gs.mode) { if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 1, 1>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 0, 1>), grid, dim3(512), 0, st, a); }
-    else if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 1>), grid, dim3(512), 0, st, a);
+    if (a.fl) hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_halo_kernel<GATHER_CONVT, 0>), grid, dim3(512), 0, st, a);
   }
   DPB_CHECK(hipGetLastError());

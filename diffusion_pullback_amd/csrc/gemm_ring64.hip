@@ -69,7 +69,7 @@ __device__ inline void wait_dma(int stages_in_flight) {   // s_waitcnt vmcnt(sta
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0, int EPI = EPI_PLAIN, int GS = 0>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; EPI: epilogue.h; GS: emits GnStat
+template <int BM, int BN, int S, int GATHER, int WAVES = 4, int FL = 0, int EPI = EPI_PLAIN>   // FL: 16-bit flavour (H16<FL>): 0 bf16, 1 f16; EPI: epilogue.h
 __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
   constexpr int BK = 64, CH = 8, KK = BK / 16;
   constexpr int NIA = BM / (8 * WAVES), NIB = BN / (8 * WAVES), U = NIA + NIB;   // DMA wave-instructions (8 rows each) per stage per wave
@@ -201,9 +201,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
     for (int i = 0; i < NIB; ++i) kcb[i] += BK;
   };
 
-  GsAcc gsa; GsCtx<FL> gsc;                       // GroupNorm statistics of the output (GnStat): plain epilogue, unsplit launches; constants fetched here, under the K loop
-  constexpr bool gs_on = EPI == EPI_PLAIN && GS != 0;
-  if constexpr (gs_on) gs_begin<FL>(p, m0 + (wave >> 1) * WM, min(n0 + (wave & 1) * WN + (lane % (WN / 8)) * 8, p.N - 8), gsc);
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -300,12 +297,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_ring64_kernel(GemmArgs p) {
       // staged rows: wave pair wy holds tile rows wy*WM + i*32 .. +31; epilogue_ln's row index wy*32 + row maps to tile row wy*WM + i*32 + row
       epilogue_ln<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + i * 32 + (wave >> 1) * (WM - 32), lnq[i]);
     } else {
-      epilogue_slab<FL, WN, SLD, EPI, GS>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb,
-                                           &gsa, &gsc);
+      epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wy * WM + i * 32, n0, (long)ksplit * gridDim.y + zb);
     }
     __syncthreads();
   });
-  if constexpr (gs_on) gs_finish<WN>(p, gsa, lane, wave, (m0 + wy * WM) / WM, n0);
 }
 
 template <int BM, int BN, int S, int WAVES, int FL>
@@ -363,11 +358,6 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
 #undef DPB_RING520
   }
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
-  else if (tile == 515 && a.gs.mode) {          // the statistics-emitting instantiation: plain rows, plain epilogue, unsplit (gemm_gs_rows)
-    const dim3 g = tiles(128, 128);
-    if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<128, 128, 2, GATHER_NONE, 4, 1, EPI_PLAIN, 1>), g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_ring64_kernel<128, 128, 2, GATHER_NONE, 4, 0, EPI_PLAIN, 1>), g, dim3(256), 0, st, a);
-  }
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);
   else launch_ring64_t<128, 128, 3>(a, tiles(128, 128), st);
   DPB_CHECK(hipGetLastError());

@@ -11,18 +11,6 @@ namespace dpb {
 // A: plain rows (lda) or gathered NHWC pixels (conv).  B is always [N][K], K contiguous.
 enum { GATHER_NONE = 0, GATHER_CONV = 1, GATHER_CONVT = 2, GATHER_UPCONV = 3 };
 enum { EPI_PLAIN = 0, EPI_GEGLU_TAN = 1, EPI_GEGLU_ADJ = 2, EPI_LN_TAN = 3, EPI_LN_ADJ = 4, EPI_GEGLU_FWD = 5 };   // fused epilogues of the ring GEMMs (epilogue.h)
-// GroupNorm statistics of a product's OUTPUT tensor, emitted by the product's own epilogue (epilogue.h, gs_*): the consumer GroupNorm then needs no
-// statistics launch.  One partial per (row block of `rb` rows = the wave's row strip, 16-byte chunk column): float4 (s1, s2 of the chunk's channels in
-// its first group, s1, s2 of those in its second group) -- a chunk of 8 channels spans at most two groups (cpg >= 8); plain stores, fixed order, and the
-// GroupNorm apply launch adds them in row-block order (norm.hip, GNArgs::ppart): bitwise reproducible like the two-pass statistics.
-struct GnStat {
-  float* part = nullptr;          // [ceil(M / rb)][N / 8][4]
-  int mode = 0;                   // 0 off | 1 primal: (sum x, sum x^2) | 2 tangent: v = out, (sum v, sum xhat v) | 3 adjoint: v = gamma silu'(y) out
-  int cpg = 0, HW = 0, kps = 1, silu = 0, G = 0;
-  const void* x = nullptr;        // modes 2, 3: primal GroupNorm input [Bp][HW][N]
-  const double* pstats = nullptr; // modes 2, 3: [Bp][G][2] (mean, rstd)
-  const float* gamma = nullptr; const float* beta = nullptr;   // mode 3
-};
 struct GemmArgs {
   const void* A = nullptr; const void* B = nullptr; void* C = nullptr; const void* R = nullptr;
   const float* bias = nullptr;
@@ -55,7 +43,6 @@ struct GemmArgs {
   // EPI_LN_ADJ adds the LayerNorm adjoint of the product (the cotangent of the LayerNorm OUTPUT) to C.  ln_x: primal LayerNorm input [prows][N]
   // (row m belongs to primal row ((m / rows_per_sample) / epi_kps) * rows_per_sample + m % rows_per_sample), ln_gamma fp32 [N]
   const void* ln_x = nullptr; const float* ln_gamma = nullptr; float ln_eps = 1e-5f; void* C2 = nullptr;
-  GnStat gs;                          // optional: statistics of the output for the GroupNorm that reads it (ring / halo kernels, plain epilogue, no split-K)
   int fl = 0;                         // 16-bit flavour of the specialised kernels: 0 bf16, 1 f16 (filled in by launch_gemm)
   int order = 0;                      // block processing order per XCD: 0 A-major, 1 B-major (weight-heavy); filled in by launch_gemm
 };
@@ -64,9 +51,7 @@ struct GemmArgs {
 // arguments (pending->splitk > 1) and the caller either hands the slabs to a consumer that reduces them itself (SlabSrc, norm.hip) or calls
 // launch_gemm_reduce; otherwise pending->splitk is set to 1.
 struct GemmPlan { int kind, tile, splitk; };   // kind: 0 / 1 register-staged 64x64 / 128x128, 2 LDS ring (tile = its code), 3 halo-tile convolution; -1 error
-// *gs_rb: rows per statistics partial block if the launch emitted a.gs (0: it did not -- the kernel picked cannot, or the product is split over K).
-int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches = nullptr, GemmArgs* pending = nullptr, int* gs_rb = nullptr);
-int gemm_gs_rows(int dtype, const GemmArgs& a, const GemmPlan& pl);   // host-only: rows per partial block the planned kernel would emit (0 = unsupported)
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* launches = nullptr, GemmArgs* pending = nullptr);
 int launch_gemm_reduce(int dtype, const GemmArgs& pending, hipStream_t st);
 GemmPlan gemm_plan(int dtype, const GemmArgs& a);   // host-only: the kernel launch_gemm picks, with its K split (clamped to the slab scratch)
 int gemm_uses_big_tile(int dtype, const GemmArgs& a);
@@ -106,9 +91,7 @@ struct GNArgs {
   size_t part_bytes = 0;
   int* ticket = nullptr;          // [n] arrival counters, zero between launches
   int det = 1;                    // 1 (default): bitwise reproducible statistics (fixed-order reductions); 0: atomics (round-1 path, A/B only)
-  int red = 0;                    // set by launch_groupnorm: the apply pass adds the statistics launch's per-block partials itself (1) or the producer's (2)
-  const float* ppart = nullptr;   // statistics partials emitted by the PRODUCER of this op's input (GnStat layout): no statistics launch
-  int prb = 0;                    // rows per partial block of ppart
+  int red = 0;                    // set by launch_groupnorm: the apply pass adds the statistics launch's per-block partials itself
   int Bp = 1, NT = 0, kps = 1;    // tangent j belongs to primal sample j / kps
   int HW = 0, C = 0, G = 32;
   float eps = 1e-5f;

@@ -94,39 +94,7 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
     for (int i = tid; i < 2 * a.G; i += 256) lsum[i] = 0.f;
     __syncthreads();
   }
-  if (!STATS && a.red == 2) {
-    // the PRODUCER of this op's input emitted the statistics from its epilogue (GnStat, epilogue.h): one float4 per (row block of prb rows, 16-byte
-    // chunk column) = (s1, s2) of the chunk's channels in its first group, (s1, s2) of those in its second group.  Statistic i = (group g, w) adds the
-    // row blocks of sample / tangent j in order, and per row block the chunk columns touching g in order; 4 fixed segments as below.
-    const int n2 = 2 * a.G, ncc = a.C / CH, nrb = a.HW / a.prb;
-    const float* pj = a.ppart + (long)j * nrb * ncc * 4;
-    for (int t = tid; t < 4 * n2; t += 256) {
-      const int q = t / n2, i = t - q * n2, g = i >> 1, w = i & 1;
-      const int c_lo = g * cpg / CH, c_hi = (g * cpg + cpg - 1) / CH;
-      const int b0 = (int)((long)nrb * q / 4), b1 = (int)((long)nrb * (q + 1) / 4);
-      double acc = 0.0;
-      // 16 row blocks x 3 chunk columns = 48 clamped loads in flight per round (one round for the 64x64 / 32x32 maps of SD at cpg = 10; a dependent
-      // round trip per (8 row blocks, column) made this prologue cost more than the statistics launch it replaces), added in (row block, column) order
-      for (int bb = b0; bb < b1; bb += 16) {
-        for (int c0 = c_lo; c0 <= c_hi; c0 += 3) {
-          float v[3][16];
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            const int c = min(c0 + cc, c_hi);
-            const int slot = (c * CH / cpg == g) ? 0 : 2;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[cc][u] = pj[((long)min(bb + u, b1 - 1) * ncc + c) * 4 + slot + w];
-          }
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) acc += (bb + u < b1 && c0 + cc <= c_hi) ? (double)v[cc][u] : 0.0;
-        }
-      }
-      lseg[q][i] = acc;
-    }
-    __syncthreads();
-  } else if (!STATS && a.red) {
+  if (!STATS && a.red) {
     // fixed-order reduction of the statistics launch's per-block partials of sample / tangent j: segment q adds blocks [q nb/4, (q+1) nb/4) in
     // block order, then the 4 segment sums are added in order -- the same bits in every block of every run
     const int nblk = gridDim.x, n2 = 2 * a.G;
@@ -147,9 +115,6 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
       lseg[q][i] = acc;
     }
     __syncthreads();
-  }
-  if (!STATS && a.red) {
-    const int n2 = 2 * a.G;
     for (int i = tid; i < n2; i += 256) {
       const double acc = ((lseg[0][i] + lseg[1][i]) + lseg[2][i]) + lseg[3][i];
       if (MODE == MODE_PRIMAL) lseg[0][i] = acc;            // raw (sum, sum of squares), finalised below
@@ -559,11 +524,6 @@ static int gn_two_pass_ppb(int HW, int n) {
   while (ppb > 8 && (long)((HW + ppb - 1) / ppb) * n < gn_blocks) ppb >>= 1;
   return ppb;
 }
-// statistics partials from the producer's epilogue (GNArgs::ppart) are usable by the two-pass apply kernel: 16-bit chunks of 8 channels spanning at
-// most two groups, whole row blocks per sample, few enough of them for every apply block to add them itself
-static bool gn_takes_producer_stats(const GNArgs& a, int CH) {
-  return a.ppart && a.prb > 0 && a.det && CH == 8 && a.C / a.G >= 8 && a.HW % a.prb == 0 && a.HW / a.prb <= 256 && !a.src.slab;
-}
 // gn_kernel's static LDS (lsum 2 KB + lseg 16 KB) + up to 48 KB dynamic = 66 KB: gfx950 (160 KB) only, like the rest of this library
 
 template <typename T, int MODE>
@@ -593,12 +553,6 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
     if (lds > 48 * 1024) { set_error("groupnorm: C=%d needs %zu bytes of LDS for the ordered reduction", a.C, lds); return -1; }
   }           // (atomic path: the caller has zeroed pstats / tstats -- one memset per pass in the engine)
   GNArgs b = a;
-  if (gn_takes_producer_stats(a, CH)) {            // the producer's epilogue left the statistics partials: the apply launch is all there is
-    b.red = 2;
-    hipLaunchKernelGGL((gn_kernel<T, MODE, false>), grid, dim3(256), 0, st, b, ppb);
-    DPB_CHECK(hipGetLastError());
-    return 0;
-  }
   b.red = a.det && (int)grid.x <= GN_RED_MAX;     // the apply blocks add the partials themselves (32 ... 256 L2-resident loads per thread quarter)
   hipLaunchKernelGGL((gn_kernel<T, MODE, true>), grid, dim3(256), lds, st, b, ppb);
   if (a.det && !b.red) hipLaunchKernelGGL((gn_reduce_kernel<MODE>), dim3(n), dim3(1024), 0, st, b, (int)grid.x);
@@ -613,7 +567,6 @@ static int gn_launch(const GNArgs& a, hipStream_t st) {
 
 int groupnorm_launches(int dtype, int mode, const GNArgs& a) {   // kernels launch_groupnorm issues (engine statistics)
   if (gn_fused_groups(a.C, a.G, a.HW, dt_chunk(dtype), dtype == DT_F32 ? 4 : 2)) return 1;
-  if (gn_takes_producer_stats(a, dt_chunk(dtype))) return 1;
   if (!a.det) return mode == MODE_PRIMAL ? 3 : 2;
   const int n = mode == MODE_PRIMAL ? a.Bp : a.NT;
   const int ppb = gn_two_pass_ppb(a.HW, n);

@@ -250,50 +250,6 @@ def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_groupnorm_statistics_from_the_producer_epilogue_match_the_statistics_launch(dtype):
-    """Round 4: the two-pass GroupNorms (64x64 / 32x32 maps) take their statistics -- primal (sum, sum of squares), tangent and adjoint
-    (mean v, mean xhat v) -- from the epilogue of the product that wrote their input (halo-tile convolution, ring GEMMs), as per-(row strip, 16-byte
-    column) partials added in a fixed order by the apply launch: no statistics launch.  Against the separate statistics launch
-    (dpb_debug_set("gn_epi_stats", 0)) at full SD-1.5 width down to the 32x32 level: same values up to the rounding of a different fp32 summation
-    order, fewer launches, and bitwise identical run to run."""
-    from diffusion_pullback_amd import PullbackUNet, configs as cf
-    from diffusion_pullback_amd import lib as L
-    lib = L.load()
-    enc = ("time_embedding", "conv_in", "down_blocks")
-    params = cf.sd_init_params(cf.SD15, seed=0, only_prefix=enc)
-    g = torch.Generator().manual_seed(3)
-    ctx = torch.randn(2, 77, 768, generator=g); z = torch.randn(2, 4, 64, 64, generator=g)
-    tap = ("down", 1)
-    net = PullbackUNet("sd", cf.SD15, params, dtype=dtype, device="cuda:0", max_batch=2, max_rank=10, upto=tap, verbose=False)
-    e = net.engine
-    # a different summation order of the statistics flips 16-bit roundings downstream: 7e-3 (bf16) / 9e-4 (fp16) measured over the ~60 layers to the
-    # tap -- the size of the bf16 engine's own noise against the fp32 oracle (TOL 4e-2 in test_gpu_fullsize.py), 8x smaller in fp16 as a rounding effect must be
-    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
-    try:
-        for B, k in [(1, 5), (2, 5), (1, 1), (2, 1)]:
-            V = torch.randn(B * k, 16384, generator=g)
-            U = torch.randn(B * k, e.tap_numel(tap), generator=g)
-            out, launches = {}, {}
-            for mode in (0, 1, 2):                                             # 2: a second run with the switch on (bitwise reproducibility)
-                L.check(lib.dpb_debug_set(b"gn_epi_stats", min(mode, 1)))
-                fw = e.forward(z[:B], 696.2727, ctx[:B], tap).clone(); lf = e.stats()[0]
-                e.primal(z[:B], 696.2727, ctx[:B], tap)
-                hp = e.read(tap).clone()
-                jv = e.jvp(tap, V).clone(); lj = e.stats()[0]
-                vj = e.vjp(tap, U).clone(); lv = e.stats()[0]
-                out[mode], launches[mode] = (fw, hp, jv, vj), (lf, lj, lv)
-            for a, b, c in zip(out[0], out[1], out[2]):
-                assert torch.isfinite(b).all()
-                assert torch.equal(b, c), (B, k)
-                for i in range(a.shape[0]):
-                    assert rel(b[i], a[i]) < tol, (B, k, i, rel(b[i], a[i]))
-            print(dtype, B, k, "launches (forward, jvp, vjp): statistics launches", launches[0], "from the producers", launches[1])
-            assert all(x < y for x, y in zip(launches[1], launches[0])), launches
-    finally:
-        L.check(lib.dpb_debug_set(b"gn_epi_stats", 1))
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_layernorm_fused_into_product_epilogue_matches_separate_kernels(dtype):
     """The 320-wide products next to a LayerNorm run on a row-complete 128 x 320 ring tile whose epilogue applies the LayerNorm tangent (proj_in /
     to_out products: h and LN'(h) leave one launch) or adjoint (adjoints of the q / k / v, cross-attention q and FF-in products: the cotangent of the
