@@ -90,6 +90,16 @@ def main():
         print(f"| `{f}` | {ms:.3f} | {100 * ms / total:.1f} % | {calls / ITERS:.1f} | " + (f"{tf:.0f} | {100 * tf / PEAK_TF:.1f} % | " if tf else "– | – | ") +
               (f"{100 * mfma[f][0] / mfma[f][1]:.1f} % | " if f in mfma and mfma[f][1] > 0 and mfma[f][0] > 0 else "– | ") +
               (f"{gb / 1e9:.2f} | {tbs:.2f} | {100 * tbs / PEAK_HBM:.0f} % |" if gb else "– | – | – |"))
+    # per-shape binding roof of the product launches: time at the MFMA peak vs time to move the unique operand bytes at the HBM peak
+    shapes = {}
+    for r in csv.DictReader(open(os.path.join(DIR, n_csv))):
+        if int(r["big"]) > 6:
+            continue
+        M, N, K, Z, g = int(r["M"]), int(r["N"]), int(r["K"]), int(r["Z"]), int(r["gather"])
+        kin = K // 9 if g in (1, 2, 3) and K % 9 == 0 and K > 72 else K              # 3x3 convolutions read each input pixel once, not nine times
+        es = 4.0 if DTYPE == "fp32" else 2.0
+        e = shapes.setdefault((KIND.get(r["big"], "gemm_kernel"), g, M, N, K, Z), [0, 0.0, 2.0 * M * N * K * Z, (M * kin + N * K + M * N) * es * Z])
+        e[0] += 1; e[1] += float(r["us"])
     gemm_ms = sum(fam[f][0] for f in gemm_fams if f in fam)
     gemm_fl = sum(flops[f] for f in gemm_fams)
     att_fams = [f for f in flops if f not in gemm_fams and f in fam]
@@ -103,6 +113,22 @@ def main():
         print(f"\nAttention kernels together (algorithmic L×L×d products per head: forward 2, tangent 5, adjoint 7 = 3 query-major + 4 key-major, "
               f"cross-attention 2): {att_fl / 1e12:.2f} TFLOP in {att_ms:.2f} ms = {att_fl / (att_ms * 1e-3) / 1e12:.0f} TFLOP/s "
               f"({100 * att_fl / (att_ms * 1e-3) / 1e12 / PEAK_TF:.1f} % of the MFMA peak); the shared-probability kernels issue fewer MFMAs than the algorithmic count.")
+    if shapes:
+        print("\n### Product launches by shape: which roof binds, and how close (HIP events, bracket-corrected)\n")
+        print("Roof time = max(flops / MFMA peak, unique operand bytes / 8 TB/s): the K <= 640 products of the 64x64 / 32x32 levels are **HBM-bound by their operands** "
+              "(arithmetic intensity ~ 100 flop/B against a ridge of 312), the rest MFMA-bound; `frac` = roof time / measured time.\n")
+        print("| kernel | gather | M x N x K | launches | us each | roof us | bound | frac of the binding roof |")
+        print("|---|---|---|---|---|---|---|---|")
+        tot_us = sum(e[1] for e in shapes.values()); tot_roof = 0.0
+        for key, e in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            t_m, t_h = e[2] / (PEAK_TF * 1e12) * 1e6, e[3] / (PEAK_HBM * 1e12) * 1e6
+            tot_roof += max(t_m, t_h) * e[0]
+            if e[1] / tot_us < 0.012:
+                continue
+            print(f"| `{key[0]}` | {key[1]} | {key[2]} x {key[3]} x {key[4]}" + (f" (x{key[5]})" if key[5] > 1 else "") +
+                  f" | {e[0]} | {e[1] / e[0]:.1f} | {max(t_m, t_h):.1f} | {'mfma' if t_m > t_h else 'hbm'} | {max(t_m, t_h) / (e[1] / e[0]):.2f} |")
+        print(f"\nAll product launches: {tot_us / 1e3:.2f} ms measured against {tot_roof / 1e3:.2f} ms of binding-roof time = **{tot_roof / tot_us:.2f}** of the roofline "
+              "(launches below 1.2 % of the product time are summed but not listed).")
     if hbm_total > 0:
         print(f"\nWhole iteration: {hbm_total / 1e9:.2f} GB of HBM traffic in {total:.2f} ms of kernel time = {hbm_total / (total * 1e-3) / 1e12:.2f} TB/s "
               f"({100 * hbm_total / (total * 1e-3) / 1e12 / PEAK_HBM:.0f} % of the HBM peak); {(gemm_fl + att_fl) / 1e12:.2f} TFLOP (products + attention) = "
