@@ -507,6 +507,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (force == 65) return 64;
   if (force == 67) return 66;
   if (force >= 512 && force <= 517) return force;
+  if (force >= 521 && force <= 523) return (a.gather == GATHER_NONE && a.epi == EPI_PLAIN) ? force : 515;
   if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
@@ -551,8 +552,8 @@ int gemm_epi_supported(int dtype, const GemmArgs& a) {
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = tile == 518 ? 256 : (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517)) ? 128 : 64;
-  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517 || tile == 518) ? 256 : T;
+  const int T = tile == 518 ? 256 : (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517) || tile == 521 || tile == 522) ? 128 : 64;
+  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517 || tile == 518) ? 256 : tile == 523 ? 128 : (tile == 521 || tile == 522) ? 64 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;

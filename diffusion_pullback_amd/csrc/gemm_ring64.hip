@@ -357,6 +357,16 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
     else { if (a.fl) DPB_RING520(1, EPI_LN_ADJ); else DPB_RING520(0, EPI_LN_ADJ); }
 #undef DPB_RING520
   }
+  else if (tile >= 521 && tile <= 523) {        // half tiles for the <= 256-tile launches of the 32x32 level (plain rows, plain epilogue): twice the blocks, 2-3 per CU
+    if (a.gather != GATHER_NONE || a.epi != EPI_PLAIN) { set_error("gemm: tile %d takes plain-row operands and the plain epilogue only", tile); return -1; }
+#define DPB_RINGH(BMV, BNV, SV) do { const dim3 g = tiles(BMV, BNV); \
+      if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<BMV, BNV, SV, GATHER_NONE, 4, 1, EPI_PLAIN>), g, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((gemm_ring64_kernel<BMV, BNV, SV, GATHER_NONE, 4, 0, EPI_PLAIN>), g, dim3(256), 0, st, a); } while (0)
+    if (tile == 521) DPB_RINGH(64, 128, 3);      // 72 KiB ring: 2 blocks per CU
+    else if (tile == 522) DPB_RINGH(64, 128, 2); // 48 KiB ring: 3 blocks per CU
+    else DPB_RINGH(128, 64, 3);
+#undef DPB_RINGH
+  }
   else if (tile == 514) launch_ring64_t<128, 128, 4>(a, tiles(128, 128), st);
   else if (tile == 515) launch_ring64_t<128, 128, 2>(a, tiles(128, 128), st);
   else launch_ring64_t<128, 128, 3>(a, tiles(128, 128), st);
