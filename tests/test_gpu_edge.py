@@ -290,6 +290,35 @@ def test_layernorm_fused_into_product_epilogue_matches_separate_kernels(dtype):
         L.check(lib.dpb_debug_set(b"ln_fuse", 1))
 
 
+def test_forward_pass_shortcuts_match_the_unfused_kernels():
+    """Round 4, dpb_forward (the DDIM / guidance loop's U-Net call) at full SD-1.5 width, batch 2: (i) GEGLU in the epilogue of the unsplit FF-in
+    products is BITWISE the product + GEGLU kernel (dpb_debug_set("geglu_fwd", 0)); (ii) the one-launch forward of the text-conditioned attention
+    layers (P recomputed in fp32 registers, V^T built in LDS) agrees with the materialised GEMM + softmax + transpose + GEMM path
+    (dpb_debug_set("cross_primal", 0)) to 16-bit rounding; both launch fewer kernels.  The net-wide fused temb / context projections are part of
+    the tape in every arm (their parity is the oracle comparison of tests/test_gpu_fullsize.py)."""
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    from diffusion_pullback_amd import lib as L
+    lib = L.load()
+    params = cf.sd_init_params(cf.SD15, seed=0, only_prefix=("time_embedding", "conv_in", "down_blocks"))
+    g = torch.Generator().manual_seed(8)
+    ctx = torch.randn(2, 77, 768, generator=g); z = torch.randn(2, 4, 64, 64, generator=g)
+    tap = ("down", 2)
+    net = PullbackUNet("sd", cf.SD15, params, dtype=torch.bfloat16, device="cuda:0", max_batch=2, max_rank=2, upto=tap, verbose=False)
+    e = net.engine
+    out = {}
+    try:
+        for key, (gf, cp) in {"both": (1, 1), "no_geglu": (0, 1), "no_cross": (1, 0)}.items():
+            L.check(lib.dpb_debug_set(b"geglu_fwd", gf)); L.check(lib.dpb_debug_set(b"cross_primal", cp))
+            out[key] = (e.forward(z, 696.2727, ctx, tap).clone(), e.stats()[0])
+    finally:
+        L.check(lib.dpb_debug_set(b"geglu_fwd", 1)); L.check(lib.dpb_debug_set(b"cross_primal", 1))
+    assert torch.isfinite(out["both"][0]).all()
+    assert torch.equal(out["both"][0], out["no_geglu"][0])
+    assert rel(out["both"][0], out["no_cross"][0]) < 2e-2
+    print("launches: all shortcuts", out["both"][1], "without the GEGLU epilogue", out["no_geglu"][1], "without the one-launch cross-attention", out["no_cross"][1])
+    assert out["both"][1] < out["no_geglu"][1] and out["both"][1] < out["no_cross"][1]
+
+
 def test_forward_only_pass_matches_the_stashing_pass_and_invalidates_it():
     """dpb_forward (the U-Net calls of the DDIM / guidance loop, edit.py:454-458): same output bits as dpb_primal + dpb_read_buffer, GEGLU inputs
     left untouched, and no stash -- dpb_jvp / dpb_vjp / dpb_pullback_iterate refuse until the next dpb_primal (no silent use of stale state)."""
