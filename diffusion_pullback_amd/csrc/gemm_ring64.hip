@@ -38,7 +38,9 @@ __device__ inline bf16x8 lds_read_frag(unsigned addr) {
 template <int N, int NA, int NB>
 __device__ inline void wait_frags(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
   static_assert((NA == 1 || NA == 2 || NA == 4 || NA == 5) && (NB == 1 || NB == 2 || (NA == 2 && (NB == 4 || NB == 5))), "fragment counts of the supported wave tiles");
-  if constexpr (NA == 1) {
+  if constexpr (NA == 1 && NB == 2) {           // 64 x 128 block tile: 32 x 64 wave tiles
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  } else if constexpr (NA == 1) {
     static_assert(NB == 1, "64x64 tile: one fragment each");
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(N));
   } else if constexpr (NA == 2 && NB == 5) {
