@@ -522,6 +522,13 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     if (t256 >= 160 && (double)t256 * 65536.0 <= 1.07 * (double)a.M * a.N) return 518;
   }
+  // Half tiles for launches that give every CU at most ONE 128x128 block (128 <= tiles < 256: the plain-row products of the 32x32 level at k = 5,
+  // 5120x640xK = 200 tiles): a lone 4-wave block has no co-resident partner to cover its barrier / fragment latency (43 us for 5120x640x2560
+  // against 8.6 us of MFMA time per tile); 64x128 tiles with a 3-stage ring (72 KiB) put two blocks on most CUs -- inside the pass 13.4 -> 11.2 us
+  // (K = 640, twenty per iteration), 30.8 -> 23.4 (K = 1920), 40.4 -> 32.8 (K = 2560); K = 5120 keeps the two-fold split of the 128x128 tile
+  // (46.5 vs 56.3 us).  128x64 tiles measure the same, the 2-stage 64x128 ring (three blocks per CU) less (profiles/r04_gemm_override_half_tiles.txt).
+  static const int half_env = getenv("DPB_HALF_TILE") ? atoi(getenv("DPB_HALF_TILE")) : 1;   // tuning switch
+  if (half_env && a.gather == GATHER_NONE && a.epi == EPI_PLAIN && a.Z1 * a.Z2 == 1 && a.K >= 512 && a.K <= 4096 && t128 >= 128 && t128 < 256) return 521;
   // BK = 64 ring (gemm_ring64.hip: whole-line DMA + in-wave fragment prefetch, 128x128 tile, 2 stages -> 2 blocks/CU):
   // ahead of the BK = 32 rings by 10-35 % from ~8 stages of K on, with split-K when the tiles leave CUs idle
   if (a.K >= 512 && (t128 >= 200 || a.K >= 2048)) return 515;

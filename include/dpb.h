@@ -167,7 +167,8 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
  * this returns that correction so that the raw bracket times can be reconstructed (raw = reported + overhead per launch). */
 int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms);
 /* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
- * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands;
+ * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands, 521 / 522 / 523 =
+ * half tiles 64x128 (3 / 2 stages) and 128x64 for plain-row operands;
  * 600: halo-tile 3x3 convolution), "gemm_splitk" (n), "gemm_kch", "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block
  * order per XCD), "gn_deterministic" (1, default: GroupNorm statistics of the two-pass kernels reduced in a fixed order -> bitwise
  * reproducible runs; 0 = the round-1 atomic statistics, A/B only), "graph_iterate" (0|1: dpb_pullback_iterate replays a captured hipGraph on a non-default stream;

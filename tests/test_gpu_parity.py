@@ -206,7 +206,7 @@ def test_dma_gemm_bitwise_equals_register_gemm():
                         got = run()
                         for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
                             assert torch.equal(a, b), f"case {(H, cin, cout, ks, stride, pad)} kernel {code} splitk {sk} {name} rep {rep}: max |d| = {(a - b).abs().max().item():.3e}"
-                for code in (512, 513, 514, 515, 516, 517, 518):     # BK=64 rings (gemm_ring64.hip): 128x128 S3, 256x128 S3, 128x128 S4 / S2, 8-wave 256x128 S3 / S2, 8-wave 256x256 (plain rows only)
+                for code in (512, 513, 514, 515, 516, 517, 518, 521, 522, 523):   # BK=64 rings (gemm_ring64.hip): 128x128 S3, 256x128 S3, 128x128 S4 / S2, 8-wave 256x128 S3 / S2, 8-wave 256x256, half tiles 64x128 S3 / S2, 128x64 S3 (the last four: plain rows only)
                     L.check(lib.dpb_debug_set(b"gemm_tile", code))
                     for rep in range(3):
                         got = run()
