@@ -507,6 +507,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (force == 65) return 64;
   if (force == 67) return 66;
   if (force >= 512 && force <= 517) return force;
+  if (force == 521 && a.epi == EPI_PLAIN && a.gather != GATHER_UPCONV) return 521;     // (also as an implicit-GEMM convolution)
   if (force >= 521 && force <= 523) return (a.gather == GATHER_NONE && a.epi == EPI_PLAIN) ? force : 515;
   if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
@@ -527,8 +528,13 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // against 8.6 us of MFMA time per tile); 64x128 tiles with a 3-stage ring (72 KiB) put two blocks on most CUs -- inside the pass 13.4 -> 11.2 us
   // (K = 640, twenty per iteration), 30.8 -> 23.4 (K = 1920), 40.4 -> 32.8 (K = 2560); K = 5120 keeps the two-fold split of the 128x128 tile
   // (46.5 vs 56.3 us).  128x64 tiles measure the same, the 2-stage 64x128 ring (three blocks per CU) less (profiles/r04_gemm_override_half_tiles.txt).
-  static const int half_env = getenv("DPB_HALF_TILE") ? atoi(getenv("DPB_HALF_TILE")) : 1;   // tuning switch
-  if (half_env && a.gather == GATHER_NONE && a.epi == EPI_PLAIN && a.Z1 * a.Z2 == 1 && a.K >= 512 && a.K <= 4096 && t128 >= 128 && t128 < 256) return 521;
+  static const int half_env = getenv("DPB_HALF_TILE") ? atoi(getenv("DPB_HALF_TILE")) : 3;   // tuning switch (bit 0 / bit 1: the two rules below)
+  if ((half_env & 1) && a.gather == GATHER_NONE && a.epi == EPI_PLAIN && a.Z1 * a.Z2 == 1 && a.K >= 512 && a.K <= 4096 && t128 >= 128 && t128 < 256) return 521;
+  // ... and for long-K products whose last 128-row tile is at most half full (M = 320 = 64 k rows of the 8x8 level at k = 5: 2.5 tiles, 17 % padded
+  // MFMAs): 64-row tiles cover M exactly, give 50 instead of 30 tiles, and the split-K plan needs 9 instead of 15 fp32 slabs for its ~450 blocks --
+  // the consumers (one-launch GroupNorm, LayerNorm) gather 40 % fewer slab bytes: 8.577 -> 8.52 ms per iteration inside the pass on the seventeen
+  // 8x8-level convolutions (22.4 -> 21.7 us each; 15 or 6 splits on the same tile: 25-27 us)
+  if ((half_env & 2) && a.epi == EPI_PLAIN && a.gather != GATHER_UPCONV && a.Z1 * a.Z2 == 1 && a.K >= 2048 && t128 < 128 && (a.M % 128) && (a.M % 128) <= 64) return 521;
   // BK = 64 ring (gemm_ring64.hip: whole-line DMA + in-wave fragment prefetch, 128x128 tile, 2 stages -> 2 blocks/CU):
   // ahead of the BK = 32 rings by 10-35 % from ~8 stages of K on, with split-K when the tiles leave CUs idle
   if (a.K >= 512 && (t128 >= 200 || a.K >= 2048)) return 515;

@@ -359,6 +359,11 @@ int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st) {
     else { if (a.fl) DPB_RING520(1, EPI_LN_ADJ); else DPB_RING520(0, EPI_LN_ADJ); }
 #undef DPB_RING520
   }
+  else if (tile == 521 && a.epi == EPI_PLAIN && (a.gather == GATHER_CONV || a.gather == GATHER_CONVT)) {   // the same half tile as an implicit-GEMM convolution
+    const dim3 g = tiles(64, 128);
+    if (a.gather == GATHER_CONV) { if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<64, 128, 3, GATHER_CONV, 4, 1, EPI_PLAIN>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_ring64_kernel<64, 128, 3, GATHER_CONV, 4, 0, EPI_PLAIN>), g, dim3(256), 0, st, a); }
+    else { if (a.fl) hipLaunchKernelGGL((gemm_ring64_kernel<64, 128, 3, GATHER_CONVT, 4, 1, EPI_PLAIN>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_ring64_kernel<64, 128, 3, GATHER_CONVT, 4, 0, EPI_PLAIN>), g, dim3(256), 0, st, a); }
+  }
   else if (tile >= 521 && tile <= 523) {        // half tiles for the <= 256-tile launches of the 32x32 level (plain rows, plain epilogue): twice the blocks, 2-3 per CU
     if (a.gather != GATHER_NONE || a.epi != EPI_PLAIN) { set_error("gemm: tile %d takes plain-row operands and the plain epilogue only", tile); return -1; }
 #define DPB_RINGH(BMV, BNV, SV) do { const dim3 g = tiles(BMV, BNV); \
