@@ -133,6 +133,7 @@ void gemm_prep(dpb_engine* e, GemmArgs& a) {
 int g_lazy_reduce = getenv("DPB_LAZY_REDUCE") ? atoi(getenv("DPB_LAZY_REDUCE")) : 1;
 // LayerNorm tangent / adjoint in the epilogue of the neighbouring 320-wide product (A/B switch: DPB_LN_FUSE=0, dpb_debug_set("ln_fuse", 0))
 int g_ln_fuse = getenv("DPB_LN_FUSE") ? atoi(getenv("DPB_LN_FUSE")) : 1;
+int g_ln_kmax = getenv("DPB_LN_FUSE_KMAX") ? atoi(getenv("DPB_LN_FUSE_KMAX")) : 1024;   // adjoint: longest K that still takes the row-complete LayerNorm tile (tuning switch)
 
 int flush_pending(dpb_engine* e) {                 // the designated consumer did not come next: reduce the parked product the ordinary way
   if (!e->pend.on) return 0;
@@ -288,7 +289,7 @@ int conv_adj(dpb_engine* e, const Op& op, int n) {
     const int gather = d.ip[9];
     // the LayerNorm that wrote this product's input: its adjoint in the epilogue (K <= 1024: beyond -- the FF-in adjoint, K = 8 C -- the
     // row-complete tile's one block per CU loses more in the K loop than the fusion saves: g_ln_fuse bit 1 forces it for A/Bs)
-    if (gather == GATHER_NONE && op.ln_prev >= 0 && g_ln_fuse && e->uses[d.in0] == 1 && (g.K <= 1024 || (g_ln_fuse & 2))) {
+    if (gather == GATHER_NONE && op.ln_prev >= 0 && g_ln_fuse && e->uses[d.in0] == 1 && (g.K <= g_ln_kmax || (g_ln_fuse & 2))) {
       const dpb_op_desc& ld = e->ops[op.ln_prev].d;
       GemmArgs f = g;
       f.M = n * bi.rows;
