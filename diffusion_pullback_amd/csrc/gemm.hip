@@ -529,7 +529,8 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // (K = 640, twenty per iteration), 30.8 -> 23.4 (K = 1920), 40.4 -> 32.8 (K = 2560); K = 5120 keeps the two-fold split of the 128x128 tile
   // (46.5 vs 56.3 us).  128x64 tiles measure the same, the 2-stage 64x128 ring (three blocks per CU) less (profiles/r04_gemm_override_half_tiles.txt).
   static const int half_env = getenv("DPB_HALF_TILE") ? atoi(getenv("DPB_HALF_TILE")) : 3;   // tuning switch (bit 0 / bit 1: the two rules below)
-  if ((half_env & 1) && a.gather == GATHER_NONE && a.epi == EPI_PLAIN && a.Z1 * a.Z2 == 1 && a.K >= 512 && a.K <= 4096 && t128 >= 128 && t128 < 256) return 521;
+  static const int half_kmin = getenv("DPB_HALF_KMIN") ? atoi(getenv("DPB_HALF_KMIN")) : 256;   // tuning switch (256: the K = 320 products of a batch-2 forward at 64x64 too: forward -0.3 %, iteration neutral)
+  if ((half_env & 1) && a.gather == GATHER_NONE && a.epi == EPI_PLAIN && a.Z1 * a.Z2 == 1 && a.K >= half_kmin && a.K <= 4096 && t128 >= 128 && t128 < 256) return 521;
   // ... and for long-K products whose last 128-row tile is at most half full (M = 320 = 64 k rows of the 8x8 level at k = 5: 2.5 tiles, 17 % padded
   // MFMAs): 64-row tiles cover M exactly, give 50 instead of 30 tiles, and the split-K plan needs 9 instead of 15 fp32 slabs for its ~450 blocks --
   // the consumers (one-launch GroupNorm, LayerNorm) gather 40 % fewer slab bytes: 8.577 -> 8.52 ms per iteration inside the pass on the seventeen
