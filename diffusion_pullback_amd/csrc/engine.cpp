@@ -1073,8 +1073,9 @@ int dpb_read_buffer(dpb_engine* e, int buf, int channels, float* out) {
   return launch_nhwc_to_nchw(e->dtype, e->P(buf), out, n, channels, b.rows, b.C, e->stream);
 }
 
-int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
-  if (!e || !V || !U) return fail("null argument");
+// U == nullptr (dpb_pullback_iterate, every iteration but the last): the tangent of the tap stays in T(tap); the adjoint pass takes it from there
+static int jvp_pass(dpb_engine* e, int tap, const float* V, int nt, float* U) {
+  if (!e || !V) return fail("null argument");
   if (int r = check_tap(e, tap, nt)) return r;
   e->n_launch = 0; e->flops = 0; e->gbytes = 0;
   const Buf& bx = e->bufs[e->x_buf];
@@ -1089,20 +1090,32 @@ int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
     if (int r = run_op(e, e->ops[i], MODE_TANGENT, nt)) return r;
   }
   if (int r = flush_pending(e)) return r;
+  if (!U) return 0;
   const Buf& bt = e->bufs[tap];
   e->n_launch++;
   return launch_nhwc_to_nchw(e->dtype, e->T(tap), U, nt, bt.Cv, bt.rows, bt.C, e->stream);
 }
 
-int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
-  if (!e || !U || !W) return fail("null argument");
+int dpb_jvp(dpb_engine* e, int tap, const float* V, int nt, float* U) {
+  if (!U) return fail("null argument");
+  return jvp_pass(e, tap, V, nt, U);
+}
+
+// U == nullptr: the cotangent seed IS the tangent the last jvp_pass left in T(tap) -- its storage is handed to G(tap) for this pass (the fp32 NCHW round
+// trip through U is the identity on 16-bit and fp32 values alike, so the results are bitwise those of the two conversion kernels it replaces)
+static int vjp_pass(dpb_engine* e, int tap, const float* U, int nt, float* W) {
+  if (!e || !W) return fail("null argument");
   if (int r = check_tap(e, tap, nt)) return r;
   e->n_launch = 0; e->flops = 0; e->gbytes = 0;
   const Buf& bt = e->bufs[tap];
   std::fill(e->ginit.begin(), e->ginit.end(), 0);
   for (auto& b : e->bufs) b.g_off = b.g_off0;
-  e->n_launch++;
-  if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
+  if (U) {
+    e->n_launch++;
+    if (int r = launch_nchw_to_nhwc(e->dtype, U, e->G(tap), nt, bt.Cv, bt.rows, bt.C, e->stream)) return r;
+  } else {
+    e->bufs[tap].g_off = e->bufs[tap].t_off;       // restored from g_off0 at the start of the next adjoint pass
+  }
   e->ginit[tap] = 1;
   if (e->tstats_bytes && !gn_deterministic()) DPB_CHECK(hipMemsetAsync(e->ws + e->tstats_off, 0, e->tstats_bytes, e->stream));
   e->cur_tap = tap; e->pend.on = false;
@@ -1116,6 +1129,11 @@ int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   const Buf& bx = e->bufs[e->x_buf];
   e->n_launch++;
   return launch_nhwc_to_nchw(e->dtype, e->G(e->x_buf), W, nt, e->x_channels, bx.rows, bx.C, e->stream);
+}
+
+int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
+  if (!U) return fail("null argument");
+  return vjp_pass(e, tap, U, nt, W);
 }
 
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N, void* stream) {
@@ -1140,6 +1158,7 @@ int dpb_orth_checked(const float* W, const float* Vprev, float* V, float* s, flo
 
 size_t dpb_orth_scratch_bytes(int k, int64_t N) { return (k < 1 || k > 56 || N < 1) ? 0 : orth_scratch_bytes(k, N); }
 
+static int g_iter_alias = getenv("DPB_ITER_ALIAS") ? atoi(getenv("DPB_ITER_ALIAS")) : 1;   // A/B switch: 0 = convert U out and back in every iteration
 static int g_graph_iterate = 0;      // dpb_debug_set("graph_iterate", 1): replay the power iteration as a captured hipGraph (measurement option)
 
 int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, float* conv, int k, int n_iters) {
@@ -1151,10 +1170,14 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
   const long N = (long)e->bufs[e->x_buf].rows * e->x_channels;
   float* Wm = (float*)(e->ws + e->pbW);
   long launches = 0; double fl = 0, gb = 0;
-  auto body = [&]() -> int {                        // one power iteration: k JVPs, k VJPs, re-orthonormalisation, V <- V_new; no host sync
-    if (int r = dpb_jvp(e, tap, V, nt, U)) return r;
+  const bool alias_ok = e->bufs[tap].Cv == e->bufs[tap].C && g_iter_alias;   // (padded tap channels: the conversion kernels zero them, an alias would not)
+  auto body = [&](bool want_u) -> int {             // one power iteration: k JVPs, k VJPs, re-orthonormalisation, V <- V_new; no host sync
+    // U = J V_prev is an OUTPUT of the last iteration only (utils.py:810): before that the tap's tangent goes straight from T(tap) into the adjoint
+    // pass -- no nhwc -> fp32 nchw -> nhwc round trip (two launches per iteration, bitwise the same values)
+    const bool keep = alias_ok && !want_u;
+    if (int r = jvp_pass(e, tap, V, nt, keep ? nullptr : U)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
-    if (int r = dpb_vjp(e, tap, U, nt, Wm)) return r;
+    if (int r = vjp_pass(e, tap, keep ? nullptr : U, nt, Wm)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
     for (int b = 0; b < B; ++b)                     // independent k x N re-orthonormalisation per sample
       if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, V + (long)b * k * N, s + b * k, conv + 2 * b,   // in place: see dpb.h
@@ -1168,13 +1191,13 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
     // every code object is loaded) and replay it.  Measured on MI355X: no gain -- the stream never runs dry.
     const dpb_engine::GraphKey key{tap, k, B, V, U, s, conv};
     if (!e->gexec || !(key == e->gkey)) {
-      if (int r = body()) return r;
+      if (int r = body(true)) return r;
       ++it;
       if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
       hipGraph_t g = nullptr;
       const long l0 = launches; const double f0 = fl, b0 = gb;
       DPB_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-      const int r = body();
+      const int r = body(true);                     // the captured iteration always writes U (it may be the last one replayed)
       const hipError_t ce = hipStreamEndCapture(e->stream, &g);
       e->g_launches = launches - l0; e->g_flops = fl - f0; e->g_bytes = gb - b0;
       launches = l0; fl = f0; gb = b0;               // captured, not executed
@@ -1190,7 +1213,7 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
     }
   }
   for (; it < n_iters; ++it)
-    if (int r = body()) return r;
+    if (int r = body(it == n_iters - 1)) return r;
   e->n_launch = launches; e->flops = fl; e->gbytes = gb;
   return 0;
 }

@@ -67,16 +67,16 @@ __global__ __launch_bounds__(64) void eig_kernel(const double* Gp, int nbg, doub
   const int r = threadIdx.x;
   for (int e = r; e < k * k; e += 64) {          // Gram matrix and overlaps: the blocks' partials added in block order
     double g = 0.0, x = 0.0;
-    for (int b0 = 0; b0 < nbg; b0 += 8) {        // eight partials of each in flight (clamped loads), then added in order
-      double tg[8], tx[8];
+    for (int b0 = 0; b0 < nbg; b0 += 32) {       // 32 partials of each in flight (clamped loads), then added in block order: two dependent rounds
+      double tg[32], tx[32];                      // for the 64 Gram blocks of a 4x64x64 latent instead of eight (one L2 round trip each on the critical path)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const long b = min(b0 + u, nbg - 1);
         tg[u] = Gp[(b * 2) * k * k + e];
         tx[u] = Gp[(b * 2 + 1) * k * k + e];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 32; ++u)
         if (b0 + u < nbg) { g += tg[u]; x += tx[u]; }
     }
     Q[e / k][e % k] = g;
