@@ -1319,6 +1319,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "ln_fuse")) { g_ln_fuse = value; return 0; }
   else if (!strcmp(key, "cross_primal")) { g_cross_primal = value; return 0; }
   else if (!strcmp(key, "geglu_fwd")) { g_geglu_fwd = value; return 0; }
+  else if (!strcmp(key, "iter_alias")) { g_iter_alias = value; return 0; }
   else return fail("unknown debug key %s", key);
   gemm_debug_set(tile, splitk, kch);
   return 0;

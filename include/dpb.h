@@ -177,7 +177,8 @@ int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms
  * no faster there), "lazy_reduce" (1, default: a split-K product consumed by a one-launch GroupNorm or a
  * LayerNorm leaves its fp32 slabs to that kernel instead of running splitk_reduce_kernel; 0 = always reduce; bitwise the same results),
  * "ln_fuse" (LayerNorm in the epilogue of the 320-wide products), "cross_primal" (1, default: the forward of a text-conditioned attention layer is
- * ONE launch; 0 = GEMM + softmax + transpose + GEMM), "geglu_fwd" (1, default: dpb_forward applies GEGLU in the epilogue of the unsplit FF-in products).
+ * ONE launch; 0 = GEMM + softmax + transpose + GEMM), "geglu_fwd" (1, default: dpb_forward applies GEGLU in the epilogue of the unsplit FF-in products), "iter_alias" (1, default: inside dpb_pullback_iterate the tap's
+ * tangent passes from the tangent to the adjoint pass on the device, U is written by the last iteration only; 0 = fp32 round trip through U every iteration; bitwise equal).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
  * kernel and split count per product shape; DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
  * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_LN_FUSE, DPB_LAZY_REDUCE, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_SHARED, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L,

@@ -98,6 +98,36 @@ def test_engine_is_bitwise_reproducible_by_default():
         L.check(L.load().dpb_debug_set(b"gn_deterministic", 1))
 
 
+def test_iterate_keeps_the_tap_tangent_on_the_device_bitwise():
+    """Inside dpb_pullback_iterate the tap's tangent J V goes from the tangent pass straight into the adjoint pass (its buffer becomes the cotangent
+    seed) and U is converted out by the LAST iteration only: bitwise the results of the fp32 NCHW round trip through U in every iteration
+    (dpb_debug_set("iter_alias", 0)), in bf16 and fp32, one and two samples, and U is still J V_prev of the last iteration."""
+    from diffusion_pullback_amd import PullbackUNet
+    from diffusion_pullback_amd import lib as L
+    from oracle import unet_sd
+    lib = L.load()
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=32, ctx_len=77)
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(2, 4, 32, 32, generator=g); ctx = torch.randn(2, 77, 768, generator=g)
+    V0 = torch.linalg.qr(torch.randn(4096, 3, generator=g))[0].T.contiguous()
+    try:
+        for dtype in (torch.bfloat16, torch.float32):
+            net = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=2, max_rank=6, upto=("mid", 0), verbose=False)
+            for B in (1, 2):
+                out = {}
+                for alias in (0, 1):
+                    L.check(lib.dpb_debug_set(b"iter_alias", alias))
+                    u, s_, v, _ = net.pullback_fixed(z[:B], 696.2727, ctx[:B], "mid", 0, 3, 4, V0)
+                    out[alias] = (u.clone(), s_.clone(), v.clone())
+                assert all(torch.equal(a, b) for a, b in zip(out[0], out[1])), (dtype, B)
+                assert torch.isfinite(out[1][0]).all() and out[1][0].abs().sum() > 0
+            del net
+    finally:
+        L.check(lib.dpb_debug_set(b"iter_alias", 1))
+
+
 def test_graph_replay_of_the_power_iteration_matches_eager_launches():
     """dpb_debug_set("graph_iterate", 1): dpb_pullback_iterate captures one iteration as a hipGraph (after an eager one) and replays it --
     the launch sequence of an iteration is fixed for fixed buffers.  Same bits as eager launches (the default path is bitwise reproducible); capture needs a
