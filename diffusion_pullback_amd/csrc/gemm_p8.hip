@@ -1,0 +1,348 @@
+// bf16 / f16 MFMA GEMM and implicit-GEMM convolution, 256 x 256 x 64 block tile, EIGHT waves in two groups that alternate between a
+// "load" segment (LDS fragment reads + LDS-DMA issue) and a "matrix" segment (8 MFMAs) -- the deep-pipelined main loop that replaces the
+// one-barrier-per-K-step rings (gemm_ring64.hip) on the large products of the path (the conv / linear stack diffusers' U-Net runs under
+// /root/reference/src/utils/utils.py:466-499).
+//
+// Why another loop structure (round-5 finding): the ring kernels wait `vmcnt` + barrier once per K step with every wave in
+// lockstep, so DMA latency, fragment latency and MFMA issue serialise inside each step; they stop at 0.17-0.30 of the MFMA peak whatever the tile.
+// Here
+//   * waves (wr, wc) = (wave >> 2, wave & 3) form a 2 x 4 grid, wave tile 128 x 64 (0.75 KB of LDS reads per 32x32x16 MFMA instead of 1 KB);
+//   * a K tile is cut into FOUR phases, one 64 x 32 quadrant pair of the wave tile each: {read fragments, issue one 16 KiB half-tile DMA,
+//     s_barrier, lgkmcnt(0), 8 MFMAs, s_barrier};
+//   * the two wave groups (wr = 0 | 1: one wave of each on every SIMD) run ONE BARRIER APART, so on each SIMD one wave issues MFMAs while its partner
+//     reads LDS / issues DMA;
+//   * DMA is waited for once per K tile with a COUNTED vmcnt (three half tiles stay in flight across the barriers), never drained.
+//
+// LDS (128 KiB, one array): operand area (A | B, 64 KiB each) x half (h: 32 KiB) x K-tile parity (d: 16 KiB) = [128 rows][64 k] 16-bit, 128-byte rows,
+// 16-byte chunk (row, c) holding logical K chunk c ^ ((row >> 1) & 7) -- the conflict-free image of gemm_ring64.hip, swizzled on the SOURCE side
+// of the DMA.  Half h of A holds block rows (r >> 6) * 128 + h * 64 + (r & 63), half h of B block columns (r >> 5) * 64 + h * 32 + (r & 31)
+// (r = row inside the half): every wave reads 64 rows of EACH A half and 32 rows of EACH B half, and its output is one contiguous 128 x 64 tile.
+//
+// Schedule of K tile s (parity d = s & 1); "read" = ds_read_b128 into registers, "stage X(t)" = 2 LDS-DMA instructions per lane for half tile X of
+// K tile t:
+//   phase 1: read B0[d] (4), A0[d] (8) | stage A1(s+1) -> A1[d^1] | lgkmcnt(8) | barrier | MFMA a0 x b0 | barrier
+//   phase 2: read B1[d] (4)            | stage B0(s+2) -> B0[d]                | barrier | MFMA a0 x b1 | barrier
+//   phase 3: read A1[d] (8)            | stage A0(s+2) -> A0[d]                | barrier | MFMA a1 x b1 | barrier
+//   phase 4:                           | stage B1(s+2) -> B1[d] | vmcnt(6)     | barrier | MFMA a1 x b0 | barrier
+// Ordering rules this satisfies (group G0 runs one barrier ahead of G1, so G0's load segment of phase q+1 overlaps G1's matrix segment of phase q):
+//   RAW  a half tile is read one phase AFTER the phase whose first barrier follows every wave's covering vmcnt: phase 4's vmcnt(6) retires the
+//        four half tiles of K tile s+1 (issued in phases 2-4 of tile s-1 and phase 1 of tile s; B0/A0/B1 of s+2 stay in flight); first read: phase 1 of s+1.
+//   WAR  a buffer is restaged two phases after its last read (A0: read 1 -> staged 3, B1: 2 -> 4, A1: 3 -> 1 of the next tile), or ONE phase after
+//        when the reads were retired before the reading phase's first barrier (B0: phase 1's lgkmcnt(8) retires the four B0 reads, issued first).
+// K tails, rows / columns beyond M / N and the two K tiles "after the end" read a 16-byte zero page, so the DMA count per phase is static.
+#include "epilogue.h"
+
+namespace dpb {
+
+typedef __attribute__((address_space(3))) void p8_lds_t;
+typedef __attribute__((address_space(1))) const void p8_gbl_t;
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 p8_read(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// s_waitcnt lgkmcnt(0) the compiler must keep between the fragment reads and the MFMAs that consume them (the fragments are threaded through it)
+__device__ __forceinline__ void p8_wait4(bf16x8 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void p8_wait8(bf16x8 (&a)[2][4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+}
+__device__ __forceinline__ void p8_wait12(bf16x8 (&a)[2][4], bf16x8 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(b[2]), "+v"(b[3]));
+}
+
+template <int GATHER, int FL, int EPI>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64, CH = 8;
+  constexpr int AREA = 65536, HALF = 32768, PAR = 16384;       // LDS bytes: operand area, half, K-tile parity
+  constexpr int WN = 64, SLD = WN + 4;
+  static_assert(8 * 32 * SLD * 4 <= 2 * AREA, "epilogue staging fits the ring");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * AREA];
+  const unsigned lds0 = (unsigned)(uintptr_t)(p8_lds_t*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // ---- block -> (tile, batch, K split): each XCD (= each L2) gets a contiguous run of the processing order (gemm_ring64.hip)
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  {
+    const int nwg = gridDim.x * gridDim.y * gridDim.z, q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  if (p.order == 0) { tn = lin % tilesN; lin /= tilesN; tm = lin % tilesM; lin /= tilesM; }
+  else { tm = lin % tilesM; lin /= tilesM; tn = lin % tilesN; lin /= tilesN; }
+  const int ksplit = lin % (int)gridDim.z, zb = lin / (int)gridDim.z;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z1 = zb / p.Z2, z2 = zb % p.Z2;
+  const bf16* A = (const bf16*)p.A + (long)(z1 / p.divA) * p.sA1 + (long)z2 * p.sA2;
+  const bf16* B = (const bf16*)p.B + (long)(z1 / p.divB) * p.sB1 + (long)z2 * p.sB2;
+  bf16* C = (bf16*)p.C + (long)z1 * p.sC1 + (long)z2 * p.sC2;
+  const bf16* R = p.R ? (const bf16*)p.R + (long)z1 * p.sR1 + (long)z2 * p.sR2 : nullptr;
+  const bf16* zero = (const bf16*)p.zeros;
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  int kt_begin = 0, nk = nk_all;
+  if (p.splitk > 1) {
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    kt_begin = ksplit * per;
+    nk = max(0, min(nk_all, kt_begin + per) - kt_begin);
+  }
+  const int kend = min(p.K, (kt_begin + nk) * BK);            // K tiles past this block's range (the two dummy tiles behind the last one) read zeros
+
+  // ---- DMA slots.  Lane's chunk inside a 1 KiB wave instruction: LDS row 8 (j*8 + wave) + (lane >> 3) of the half, physical chunk lane & 7;
+  // the swizzle key (row >> 1) & 7 = ((wave & 1) << 2) | ((lane >> 4) & 3) is the same for every slot of the lane, so is its K offset kl.
+  const int kl = ((lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3))) * CH;
+  const int Cin = p.Cin, Wd = p.W, Hd = p.H, lda = p.lda, strd = p.stride, pad = p.pad, KS = p.KS;
+  const bf16* a_base[4];             // slot sa = h*2 + j
+  const bf16* a_cur[4];
+  int a_oyx[4];
+  int kca[2], tapa[2], cca[2];       // per half: the two slots of a half advance together
+  auto retap = [&](int sa, int tap) {
+    if constexpr (GATHER == GATHER_NONE) {
+      a_cur[sa] = a_base[sa];
+    } else {
+      int ky = 0, kx = 0;
+      if (KS == 3) { ky = (tap * 11) >> 5; kx = tap - ky * 3; }
+      const int oy = a_oyx[sa] >> 16, ox = a_oyx[sa] & 0xffff;
+      int iy, ix;
+      bool ok = a_base[sa] != nullptr;
+      if constexpr (GATHER == GATHER_CONV) {
+        iy = oy * strd + ky - pad;
+        ix = ox * strd + kx - pad;
+        ok = ok && iy >= 0 && iy < Hd && ix >= 0 && ix < Wd;
+      } else if constexpr (GATHER == GATHER_CONVT) {
+        int ty = oy + pad - ky, tx = ox + pad - kx;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (strd == 2) { ok = ok && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; } else { iy = ty; ix = tx; }
+        ok = ok && iy < Hd && ix < Wd;
+      } else {
+        int uy = oy + ky - 1, ux = ox + kx - 1;
+        ok = ok && uy >= 0 && ux >= 0 && uy < 2 * Hd && ux < 2 * Wd;
+        iy = uy >> 1; ix = ux >> 1;
+      }
+      a_cur[sa] = ok ? a_base[sa] + ((long)iy * Wd + ix) * lda : nullptr;
+    }
+  };
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    kca[h] = kt_begin * BK + kl;
+    tapa[h] = 0;
+    cca[h] = kca[h];
+    if constexpr (GATHER != GATHER_NONE) {
+      tapa[h] = kca[h] / Cin;
+      cca[h] = kca[h] - tapa[h] * Cin;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int sa = h * 2 + j, r = (j * 8 + wave) * 8 + (lane >> 3);
+      const int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      a_oyx[sa] = 0;
+      if constexpr (GATHER == GATHER_NONE) {
+        a_base[sa] = m < p.M ? A + (long)m * lda : nullptr;
+      } else {
+        const int hw = p.Ho * p.Wo, smp = m / hw, rem = m - smp * hw, oy = rem / p.Wo;
+        a_oyx[sa] = (oy << 16) | (rem - oy * p.Wo);
+        a_base[sa] = m < p.M ? A + (long)smp * Hd * Wd * lda : nullptr;
+      }
+      retap(sa, tapa[h]);
+    }
+  }
+  const bf16* b_base[4];
+  int kcb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    kcb[h] = kt_begin * BK + kl;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (j * 8 + wave) * 8 + (lane >> 3);
+      const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+      b_base[h * 2 + j] = n < p.N ? B + (long)n * p.ldb : nullptr;
+    }
+  }
+  // stage the next K tile of half h of A / B into parity d (2 DMA instructions)
+  auto stage_a = [&](auto hc, auto dc) {
+    constexpr int h = decltype(hc)::value, d = decltype(dc)::value;
+    char* dst = smem + h * HALF + d * PAR + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16* src = (a_cur[h * 2 + j] && kca[h] < kend) ? a_cur[h * 2 + j] + cca[h] : zero;
+      __builtin_amdgcn_global_load_lds((p8_gbl_t*)src, (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
+    }
+    kca[h] += BK;
+    cca[h] += BK;
+    if constexpr (GATHER != GATHER_NONE) {
+      if (cca[h] >= Cin) {                         // next filter tap (uniform across the wave when Cin % 64 == 0)
+        do { cca[h] -= Cin; ++tapa[h]; } while (cca[h] >= Cin);
+        retap(h * 2, tapa[h]);
+        retap(h * 2 + 1, tapa[h]);
+      }
+    }
+  };
+  auto stage_b = [&](auto hc, auto dc) {
+    constexpr int h = decltype(hc)::value, d = decltype(dc)::value;
+    char* dst = smem + AREA + h * HALF + d * PAR + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16* src = (b_base[h * 2 + j] && kcb[h] < kend) ? b_base[h * 2 + j] + kcb[h] : zero;
+      __builtin_amdgcn_global_load_lds((p8_gbl_t*)src, (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
+    }
+    kcb[h] += BK;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- fragment read addresses: row (wr*64 | wc*32) + l31 of a half, K16 substep kk: chunk (2 kk + lhi) ^ ((l31 >> 1) & 7); half / parity / the
+  // second 32-row fragment are immediate offsets
+  const int l31 = lane & 31, lhi = lane >> 5;
+  unsigned adA[4], adB[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const unsigned ko = (unsigned)(((2 * kk + lhi) ^ ((l31 >> 1) & 7)) << 4);
+    adA[kk] = lds0 + (wr * 64 + l31) * 128 + ko;
+    adB[kk] = lds0 + AREA + (wc * 32 + l31) * 128 + ko;
+  }
+
+  f32x16 acc[2][2][2];               // [A half][32-row fragment][B half]
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][i][y][r] = 0.f;
+  bf16x8 fa[2][4], fb0[4], fb1[4];
+
+  auto read_a = [&](auto hc, auto dc) {
+    constexpr int o = decltype(hc)::value * HALF + decltype(dc)::value * PAR;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      fa[0][kk] = p8_read<o>(adA[kk]);
+      fa[1][kk] = p8_read<o + 4096>(adA[kk]);
+    }
+  };
+  auto read_b = [&](auto hc, auto dc, bf16x8 (&fb)[4]) {
+    constexpr int o = decltype(hc)::value * HALF + decltype(dc)::value * PAR;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fb[kk] = p8_read<o>(adB[kk]);
+  };
+  auto mma = [&](auto xc, auto yc, bf16x8 (&fb)[4]) {
+    constexpr int x = decltype(xc)::value, y = decltype(yc)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      acc[x][0][y] = H16<FL>::mfma(fa[0][kk], fb[kk], acc[x][0][y]);
+      acc[x][1][y] = H16<FL>::mfma(fa[1][kk], fb[kk], acc[x][1][y]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto ktile = [&](auto dc) {
+    using D = decltype(dc);
+    using DX = std::integral_constant<int, D::value ^ 1>;
+    // phase 1
+    read_b(I0{}, D{}, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(I0{}, D{});
+    stage_a(I1{}, DX{});
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the four B0 reads (issued first) are done: B0[d] may be restaged in phase 2
+    bar();
+    p8_wait12(fa, fb0);
+    mma(I0{}, I0{}, fb0);
+    bar();
+    // phase 2
+    read_b(I1{}, D{}, fb1);
+    stage_b(I0{}, D{});
+    bar();
+    p8_wait4(fb1);
+    mma(I0{}, I1{}, fb1);
+    bar();
+    // phase 3
+    read_a(I1{}, D{});
+    stage_a(I0{}, D{});
+    bar();
+    p8_wait8(fa);
+    mma(I1{}, I1{}, fb1);
+    bar();
+    // phase 4
+    stage_b(I1{}, D{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // K tile s+1 has landed (this wave's share); B0 / A0 / B1 of s+2 stay in flight
+    bar();
+    mma(I1{}, I0{}, fb0);
+    bar();
+  };
+
+  if (nk > 0) {
+    stage_b(I0{}, I0{}); stage_a(I0{}, I0{}); stage_b(I1{}, I0{}); stage_a(I1{}, I0{});      // K tile 0
+    stage_b(I0{}, I1{}); stage_a(I0{}, I1{}); stage_b(I1{}, I1{});                            // K tile 1 without its A1 half (phase 1 of tile 0)
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    bar();
+    if (wr == 1) bar();                              // group 1 runs one barrier behind group 0 from here on
+    for (int s = 0; s < nk; s += 2) {
+      ktile(I0{});
+      if (s + 1 >= nk) break;
+      ktile(I1{});
+    }
+    if (wr == 0) bar();
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue through LDS: 32 accumulator rows per wave at a time -> 16-byte row-contiguous stores (epilogue.h).  epilogue_slab places a wave
+  // at columns n0 + (wave & 1) * 64 of its n0: hand it the 128-column pair base of this wave.
+  float* stg = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
+  const int n0w = n0 + (wc >> 1) * 128;
+  static_for<0, 4>([&](auto ic) {
+    constexpr int x = decltype(ic)::value >> 1, i = decltype(ic)::value & 1;
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + y * 32 + l31] = acc[x][i][y][r];
+    __syncthreads();
+    epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wr * 128 + x * 64 + i * 32, n0w, (long)ksplit * gridDim.y + zb);
+    __syncthreads();
+  });
+}
+
+template <int FL>
+static void launch_p8_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.gather) {
+    case GATHER_NONE:
+      if (a.epi == EPI_GEGLU_TAN) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_GEGLU_TAN>), grid, dim3(512), 0, st, a);
+      else if (a.epi == EPI_GEGLU_ADJ) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_GEGLU_ADJ>), grid, dim3(512), 0, st, a);
+      else if (a.epi == EPI_GEGLU_FWD) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_GEGLU_FWD>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a);
+      break;
+    case GATHER_CONV: hipLaunchKernelGGL((gemm_p8_kernel<GATHER_CONV, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a); break;
+    case GATHER_CONVT: hipLaunchKernelGGL((gemm_p8_kernel<GATHER_CONVT, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_p8_kernel<GATHER_UPCONV, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a); break;
+  }
+}
+
+// tile code 530: 256 x 256 x 64, 8 waves, 4 phases per K tile
+int launch_gemm_p8(const GemmArgs& a, int tile, hipStream_t st) {
+  if (tile != 530) { set_error("gemm: unknown 8-phase tile code %d", tile); return -1; }
+  if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ || (a.epi != EPI_PLAIN && a.gather != GATHER_NONE)) { set_error("gemm: the 8-phase tile has the plain and GEGLU epilogues only"); return -1; }
+  const int sk = a.splitk > 1 ? a.splitk : 1;
+  const dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256), a.Z1 * a.Z2, sk);
+  if (a.fl) launch_p8_f<1>(a, grid, st);
+  else launch_p8_f<0>(a, grid, st);
+  DPB_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dpb

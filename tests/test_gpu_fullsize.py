@@ -394,6 +394,105 @@ def test_ddpm256_headline_vs_reference_function_golden():
     _check_vs_reference(fix, s, vT, torch.float32)
 
 
+# ------------------------------------------------------------------------------------------------ the TIMED loop (dpb_pullback_iterate) vs the REFERENCE's own function
+def _reference_v0(fix, n_in, k):
+    """The V0 the reference draws under the fixture's seed (utils.py:750-753: qr of a CPU randn(n_in, k))."""
+    torch.manual_seed(fix["rng_seed"])
+    q, _ = torch.linalg.qr(torch.randn(n_in, k, dtype=torch.float))
+    return q.T.contiguous()
+
+
+def _check_u(fix, u, dtype, head=True):
+    un = u.float().cpu().norm(dim=0)
+    assert torch.allclose(un, fix["u_norms"], rtol=1e-3 if dtype == torch.float32 else 3e-2), (un, fix["u_norms"])
+    if head and "u_head" in fix:
+        uh, rh = u[:256].float().cpu(), fix["u_head"]
+        sign = torch.sign((uh * rh).sum(0, keepdim=True))
+        assert rel(uh * sign, rh) < (2e-3 if dtype == torch.float32 else 1e-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_sd15_fused_iterate_vs_reference_function_golden(dtype):
+    """The path bench.py times (dpb_primal + dpb_pullback_iterate = pullback_fixed: JVP, VJP and re-orthonormalisation of all 12 iterations chained
+    on the device, tangent aliasing included) against (u, s, vT) RETURNED BY THE REFERENCE'S OWN utils.local_encoder_pullback_zt (utils.py:756-810)
+    on the full-size SD-v1.5 net -- same fixture, same bars as the host-driven loop above, no transitivity through the toy nets."""
+    from _util import load_golden
+    fix = load_golden("pullback_sd15_mid_k5.pt")
+    assert fix["iters"] == 12 and fix["k"] == 5
+    z, ctx = _sd15_inputs()
+    net = _sd15(dtype)
+    u, s, vT, _ = net.pullback_fixed(z, T_SD, ctx, "mid", 0, 5, 12, _reference_v0(fix, 16384, 5))
+    _check_vs_reference(fix, s, vT, dtype)
+    _check_u(fix, u, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_sd21_base_k2_fused_iterate_vs_reference_function_golden(dtype):
+    from _util import load_golden
+    fix = load_golden("pullback_sd21_mid_k2.pt")
+    z, ctx = _sd21_inputs()
+    net = _sd21(dtype)
+    u, s, vT, _ = net.pullback_fixed(z, T_SD, ctx, "mid", 0, 2, 12, _reference_v0(fix, 16384, 2))
+    _check_vs_reference(fix, s, vT, dtype)
+    _check_u(fix, u, dtype, head=False)
+
+
+def test_ddpm256_fused_iterate_vs_reference_function_golden():
+    from _util import load_golden
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    fix = load_golden("pullback_ddpm256_mid_k5.pt")
+    cfg = cf.CELEBA_HQ_256
+    params = cf.ddpm_init_params(cfg, seed=0, spectrum=cf.Spectrum())
+    net = PullbackUNet("ddpm", cfg, params, dtype=torch.float32, device=DEV, max_batch=1, max_rank=5, upto=("mid", 0), verbose=False)
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+    u, s, vT, _ = net.pullback_fixed(x, 600.0, None, "mid", 0, 5, 12, _reference_v0(fix, 196608, 5))
+    _check_vs_reference(fix, s, vT, torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ the batched forward-only pass (the DDIM / edit loop's U-Net call)
+@pytest.mark.parametrize("dtype,B", [(torch.bfloat16, 2), (torch.bfloat16, 5), (torch.float16, 2), (torch.float16, 5)], ids=["bf16-B2", "bf16-B5", "fp16-B2", "fp16-B5"])
+def test_sd15_forward_only_eps_vs_oracle(dtype, B):
+    """engine.forward(z, t, ctx, "eps") -- what DDIMforwardsteps / x_space_guidance call per step (/root/reference/src/modules/edit.py:454-458,
+    :484-502), with the forward-only shortcuts (fused temb / context projections, one-launch cross-attention, GEGLU epilogue, output head) -- at the
+    CLI's batch sizes and full SD-1.5 size, per sample against the CPU oracle's whole U-Net (stop=None)."""
+    from oracle import unet_sd
+    _threads()
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(B, 4, 64, 64, generator=g)
+    ctx = torch.randn(B, 77, 768, generator=g)
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    net = PullbackUNet("sd", cf.SD15, _sd15_params(True), dtype=dtype, device=DEV, max_batch=B, max_rank=B, upto=None, verbose=False)   # whole U-Net, output head included
+    eps = net.engine.forward(z, T_SD, ctx, "eps").float().cpu()
+    assert eps.shape == (B, 4, 64, 64)
+    p = _sd15_params(True)
+    picks = [0, B - 1] if B > 2 else [0, 1]
+    for i in picks:                                           # first and last sample of the batch (distinct inputs and contexts)
+        with torch.no_grad():
+            ref = unet_sd.forward(p, unet_sd.SD15, z[i:i + 1], torch.tensor(T_SD), ctx[i:i + 1], stop=None)
+        assert rel(eps[i:i + 1], ref) < TOL[dtype], (i, rel(eps[i:i + 1], ref))
+    # the batch is not one sample repeated, and rows do not leak across samples: sample 0 alone gives the same eps as inside the batch (16-bit rounding)
+    solo = net.engine.forward(z[:1], T_SD, ctx[:1], "eps").float().cpu()
+    assert rel(solo, eps[:1]) < TOL[dtype]
+    assert rel(eps[:1], eps[1:2]) > 0.1
+
+
+def test_sd21_forward_only_eps_vs_oracle_fp16_b2():
+    from oracle import unet_sd
+    _threads()
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(2, 4, 64, 64, generator=g)
+    ctx = torch.randn(2, 77, 1024, generator=g)
+    from diffusion_pullback_amd import PullbackUNet, configs as cf
+    net = PullbackUNet("sd", cf.sd_config_for("stabilityai/stable-diffusion-2-1-base"), _sd21_params(True), dtype=torch.float16, device=DEV, max_batch=2,
+                       max_rank=2, upto=None, verbose=False)
+    eps = net.engine.forward(z, T_SD, ctx, "eps").float().cpu()
+    p = _sd21_params(True)
+    for i in (0, 1):
+        with torch.no_grad():
+            ref = unet_sd.forward(p, unet_sd.SD21_BASE, z[i:i + 1], torch.tensor(T_SD), ctx[i:i + 1], stop=None)
+        assert rel(eps[i:i + 1], ref) < TOL[torch.float16], (i, rel(eps[i:i + 1], ref))
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE configs[4]: the criterion at down / up taps
 @pytest.mark.parametrize("tap", [("down", 1), ("up", 3)], ids=["down1", "up3"])
 def test_sd15_config4_top5_fp16_vs_fp32_at_down_and_up_taps(tap):
