@@ -510,7 +510,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (force == 521 && a.epi == EPI_PLAIN && a.gather != GATHER_UPCONV) return 521;     // (also as an implicit-GEMM convolution)
   if (force >= 521 && force <= 523) return (a.gather == GATHER_NONE && a.epi == EPI_PLAIN) ? force : 515;
   if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
-  if (force == 530) return (a.epi == EPI_PLAIN || a.gather == GATHER_NONE) ? 530 : 515;
+  if (force >= 530 && force <= 538) return (a.epi == EPI_PLAIN || a.gather == GATHER_NONE) ? force : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
@@ -560,15 +560,15 @@ int gemm_epi_supported(int dtype, const GemmArgs& a) {
   if (dtype == DT_F32 || a.Z1 * a.Z2 != 1 || a.gather != GATHER_NONE || a.N % 128 || a.M <= 0) return 0;
   if (a.epi == EPI_GEGLU_ADJ && a.N % 64) return 0;
   const int dt = gemm_uses_dma(dtype, a);
-  if (dt == 518 || dt == 530) return a.N % 256 == 0;
+  if (dt == 518 || dt >= 530) return a.N % 256 == 0;
   return dt == 128 || dt == 130 || dt == 132 || dt == 256 || (dt >= 512 && dt <= 517);
 }
 
 // split-K for the ring kernels: long-K problems that leave CUs idle (weights then stream from HBM once, in parallel)
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
   if (!a.slab) return 1;
-  const int T = (tile == 518 || tile == 530) ? 256 : (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517) || tile == 521 || tile == 522) ? 128 : 64;
-  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517 || tile == 518 || tile == 530) ? 256 : tile == 523 ? 128 : (tile == 521 || tile == 522) ? 64 : T;
+  const int T = (tile == 518 || tile >= 530) ? 256 : (tile == 128 || tile == 130 || tile == 132 || tile == 256 || (tile >= 512 && tile <= 517) || tile == 521 || tile == 522) ? 128 : 64;
+  const int TMm = (tile == 256 || tile == 513 || tile == 516 || tile == 517 || tile == 518 || tile >= 530) ? 256 : tile == 523 ? 128 : (tile == 521 || tile == 522) ? 64 : T;
   const long tiles = (long)((a.M + TMm - 1) / TMm) * ((a.N + T - 1) / T) * a.Z1 * a.Z2;
   const int nk = (a.K + 31) / 32;
   long s;

@@ -7,6 +7,7 @@ import torch
 from gpu_gemm_bench import conv_engine, run, lib, L, DEV
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+TILE = int(os.environ.get("P8_TILE", "530"))          # which 8-phase variant to check
 
 
 def out_of(e, x, tile, sk):
@@ -26,7 +27,7 @@ for dt in (torch.bfloat16, torch.float16):
         e = conv_engine(H, cin, cout, ks, dt, b)
         x = torch.randn(b, cin, H, H, device=DEV)
         ref = out_of(e, x, 515, sk)
-        new = out_of(e, x, 530, sk)
+        new = out_of(e, x, TILE, sk)
         eq = torch.equal(ref, new)
         md = (ref.float() - new.float()).abs().max().item()
         bad += not eq
@@ -39,16 +40,18 @@ for dt in (torch.bfloat16, torch.float16):
 for (H, cin, cout, ks, b) in [(16, 256, 256, 1, 1), (16, 512, 512, 1, 2), (64, 2560, 2560, 1, 1), (32, 640, 640, 3, 5)]:
     e = conv_engine(H, cin, cout, ks, torch.bfloat16, b)
     x = torch.randn(b, cin, H, H, device=DEV)
-    first = out_of(e, x, 530, 1)
+    first = out_of(e, x, TILE, 1)
     ref = out_of(e, x, 515, 1)
     diffs = 0
     for _ in range(10 if quick else 30):
-        diffs += not torch.equal(out_of(e, x, 530, 1), first)
+        diffs += not torch.equal(out_of(e, x, TILE, 1), first)
     bad += diffs + (not torch.equal(first, ref))
     print(f"race screen M={b*H*H} N={cout} K={ks*ks*cin}: {diffs} runs differ from the first; first equals ring: {torch.equal(first, ref)}", flush=True)
     del e
 L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
-print("P8 CHECK", "FAILED" if bad else "OK", bad, flush=True)
+print("P8 CHECK", TILE, "FAILED" if bad else "OK", bad, flush=True)
+if os.environ.get("P8_NOTIME"):
+    sys.exit(1 if bad else 0)
 
 V = ((515, 1, 4), (518, 1, 4), (530, 1, 4))
 run("lin 64^2 2560->2560 b5", 64, 2560, 2560, 1, 5, variants=V)
