@@ -510,7 +510,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (force == 521 && a.epi == EPI_PLAIN && a.gather != GATHER_UPCONV) return 521;     // (also as an implicit-GEMM convolution)
   if (force >= 521 && force <= 523) return (a.gather == GATHER_NONE && a.epi == EPI_PLAIN) ? force : 515;
   if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
-  if (force >= 530 && force <= 538) return (a.epi == EPI_PLAIN || a.gather == GATHER_NONE) ? force : 515;
+  if (force == 530) return ((a.epi == EPI_PLAIN || a.gather == GATHER_NONE) && (a.gather == GATHER_NONE || a.Cin % 64 == 0)) ? 530 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds

@@ -19,17 +19,23 @@
 // (r = row inside the half): every wave reads 64 rows of EACH A half and 32 rows of EACH B half, and its output is one contiguous 128 x 64 tile.
 //
 // Schedule of K tile s (parity d = s & 1); "read" = ds_read_b128 into registers, "stage X(t)" = 2 LDS-DMA instructions per lane for half tile X of
-// K tile t:
-//   phase 1: read B0[d] (4), A0[d] (8) | stage A1(s+1) -> A1[d^1] | lgkmcnt(8) | barrier | MFMA a0 x b0 | barrier
-//   phase 2: read B1[d] (4)            | stage B0(s+2) -> B0[d]                | barrier | MFMA a0 x b1 | barrier
-//   phase 3: read A1[d] (8)            | stage A0(s+2) -> A0[d]                | barrier | MFMA a1 x b1 | barrier
-//   phase 4:                           | stage B1(s+2) -> B1[d] | vmcnt(6)     | barrier | MFMA a1 x b0 | barrier
+// K tile t; fragment reads are balanced 8 / 4 / 8 / 4 over the phases (B0 of the NEXT K tile is read in phase 4):
+//   phase 1: read A0[d] (8)     | stage A1(s+1) -> A1[d^1]               | barrier | lgkmcnt(0) | MFMA a0 x b0 | barrier
+//   phase 2: read B1[d] (4)     | stage B0(s+2) -> B0[d]                 | barrier | lgkmcnt(0) | MFMA a0 x b1 | barrier
+//   phase 3: read A1[d] (8)     | stage A0(s+2) -> A0[d]   | vmcnt(10)   | barrier | lgkmcnt(0) | MFMA a1 x b0 | barrier
+//   phase 4: read B0[d^1] (4)   | stage B1(s+2) -> B1[d]   | vmcnt(6)    | barrier |              MFMA a1 x b1 | lgkmcnt(0) | barrier
 // Ordering rules this satisfies (group G0 runs one barrier ahead of G1, so G0's load segment of phase q+1 overlaps G1's matrix segment of phase q):
-//   RAW  a half tile is read one phase AFTER the phase whose first barrier follows every wave's covering vmcnt: phase 4's vmcnt(6) retires the
-//        four half tiles of K tile s+1 (issued in phases 2-4 of tile s-1 and phase 1 of tile s; B0/A0/B1 of s+2 stay in flight); first read: phase 1 of s+1.
-//   WAR  a buffer is restaged two phases after its last read (A0: read 1 -> staged 3, B1: 2 -> 4, A1: 3 -> 1 of the next tile), or ONE phase after
-//        when the reads were retired before the reading phase's first barrier (B0: phase 1's lgkmcnt(8) retires the four B0 reads, issued first).
-// K tails, rows / columns beyond M / N and the two K tiles "after the end" read a 16-byte zero page, so the DMA count per phase is static.
+//   RAW  a half tile is read one phase AFTER the phase whose FIRST barrier follows every wave's covering vmcnt (nothing else orders a ds_read behind
+//        another wave's LDS-DMA): phase 3's vmcnt(10) retires B0(s+1), issued five phases earlier -> read in phase 4; phase 4's vmcnt(6) retires
+//        A0 / B1 / A1 of K tile s+1 (B0 / A0 / B1 of s+2 stay in flight) -> read in phases 1-3 of tile s+1.
+//   WAR  a buffer is restaged two phases after its last read, whose lgkmcnt(0) precedes the reading phase's SECOND barrier (A0: read 1 -> staged 3,
+//        B1: 2 -> 4, A1: 3 -> 1 of the next tile, B0[d]: read in phase 4 of tile s-1 -> staged in phase 2 of tile s).
+// Rows / columns beyond M / N, K tails and the two K tiles "after the end" still issue their DMA (from a clamped row, the block's last K tile or a
+// 16-byte zero page), so the DMA count per phase -- and with it every counted wait -- is static.
+//
+// Measured (profiles/r05_p8_variants.txt): 1.22 PF/s on 65536 x 2560 x 2560 (ring tiles: 1.00), bitwise equal to the ring kernel.  Variants tried and
+// dropped there: the guide's 12 / 4 / 8 / 0 read schedule (equal), DMA issued inside the matrix segment with the waves taking turns (equal), one M0
+// value per half tile (equal).  Loop ablation: the load path alone takes longer than the matrix path alone (L2 -> LDS at ~40 B/clk/CU).
 #include "epilogue.h"
 
 namespace dpb {
@@ -56,16 +62,17 @@ __device__ __forceinline__ void p8_wait12(bf16x8 (&a)[2][4], bf16x8 (&b)[4]) {
                  "+v"(b[2]), "+v"(b[3]));
 }
 
-// FAST (plain rows, K % 64 == 0): the DMA source is a wave-uniform 64-bit base (SGPR pair, advanced by SALU) + a loop-invariant 32-bit lane offset --
-// no vector instruction per DMA.  Rows / columns beyond M / N read the last valid row (their products are never stored), K tiles behind the
-// block's range re-read its last tile (they are never multiplied).
-// SCHED 1: fragment reads balanced 8 / 4 / 8 / 4 over the phases (B0 of the NEXT K tile is read in phase 4, behind a second, relaxed counted wait).
-// ABL (micro-benchmark builds only, tools/gpu_p8_ab.py): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMA
-// LAY 1: a wave's two DMA pieces of a half tile are ADJACENT in LDS (piece wave*2 + j instead of j*8 + wave), the second one addressed through the
-// instruction's immediate offset (which moves the LDS and the global address alike: the source pointer is biased by -1 KiB) -- one M0 value per half tile.
-template <int GATHER, int FL, int EPI, int FAST = 0, int SCHED = 0, int ABL = 0, int LAY = 0>
+#ifndef DPB_P8_ABLATE
+#define DPB_P8_ABLATE 0   // micro-benchmark builds only (make ablate_p8, tools/gpu_p8_ablate.py): 1 no DMA in the K loop, 2 no fragment reads, 4 no MFMA
+#endif
+
+// FAST (plain rows, K % 64 == 0): the DMA source is a wave-uniform 64-bit base (SGPR pair, advanced by SALU) + a loop-invariant lane offset -- one
+// vector instruction per DMA instead of four (+4-5 %).  Rows / columns beyond M / N read the last valid row (their products are never stored), K tiles
+// behind the block's range re-read its last tile (they are never multiplied).
+template <int GATHER, int FL, int EPI, int FAST>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   static_assert(!FAST || GATHER == GATHER_NONE, "uniform-base addressing is for plain rows");
+  constexpr int ABL = DPB_P8_ABLATE;
   constexpr int BM = 256, BN = 256, BK = 64, CH = 8;
   constexpr int AREA = 65536, HALF = 32768, PAR = 16384;       // LDS bytes: operand area, half, K-tile parity
   constexpr int WN = 64, SLD = WN + 4;
@@ -106,11 +113,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
 
   // ---- DMA slots.  Lane's chunk inside a 1 KiB wave instruction: LDS row 8 (j*8 + wave) + (lane >> 3) of the half, physical chunk lane & 7;
   // the swizzle key (row >> 1) & 7 = ((wave & 1) << 2) | ((lane >> 4) & 3) is the same for every slot of the lane, so is its K offset kl.
-  auto piece = [&](int j) { return LAY ? wave * 2 + j : j * 8 + wave; };
-  int klj[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) klj[j] = ((lane & 7) ^ (((piece(j) * 8 + (lane >> 3)) >> 1) & 7)) * CH;
-  const int kl = klj[0], dkl = klj[1] - klj[0];     // (LAY 0: dkl = 0)
+  const int kl = ((lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3))) * CH;
   const int Cin = p.Cin, Wd = p.W, Hd = p.H, lda = p.lda, strd = p.stride, pad = p.pad, KS = p.KS;
   const bf16* a_base[4];             // slot sa = h*2 + j
   const bf16* a_cur[4];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int sa = h * 2 + j, r = piece(j) * 8 + (lane >> 3);
+      const int sa = h * 2 + j, r = (j * 8 + wave) * 8 + (lane >> 3);
       const int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
       a_oyx[sa] = 0;
       if constexpr (GATHER == GATHER_NONE) {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     kcb[h] = kt_begin * BK + kl;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int r = piece(j) * 8 + (lane >> 3);
+      const int r = (j * 8 + wave) * 8 + (lane >> 3);
       const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
       b_base[h * 2 + j] = n < p.N ? B + (long)n * p.ldb : nullptr;
     }
@@ -190,10 +193,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
       kua[h] = kub[h] = kt_begin * (BK * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int r = piece(j) * 8 + (lane >> 3);
+        const int r = (j * 8 + wave) * 8 + (lane >> 3);
         const int m = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1), n = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
-        aoff[h * 2 + j] = (unsigned)((m - m0) * lda + klj[j]) * 2u;
-        boff[h * 2 + j] = (unsigned)((n - n0) * p.ldb + klj[j]) * 2u;
+        aoff[h * 2 + j] = (unsigned)((m - m0) * lda + kl) * 2u;
+        boff[h * 2 + j] = (unsigned)((n - n0) * p.ldb + kl) * 2u;
       }
     }
   }
@@ -202,52 +205,46 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   auto stage_a = [&](auto hc, auto dc) {
     constexpr int h = decltype(hc)::value, d = decltype(dc)::value;
     if ((ABL & 1) && in_loop) return;
-    char* dst = smem + h * HALF + d * PAR + piece(0) * 1024;
+    char* dst = smem + h * HALF + d * PAR + wave * 1024;
     if constexpr (FAST) {
       const char* sb = Ab + min(kua[h], kumax);
-      __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)aoff[h * 2]), (p8_lds_t*)dst, 16, 0, 0);
-      if constexpr (LAY) __builtin_amdgcn_global_load_lds((p8_gbl_t*)((sb - 1024) + (unsigned long)aoff[h * 2 + 1]), (p8_lds_t*)dst, 16, 1024, 0);
-      else __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)aoff[h * 2 + 1]), (p8_lds_t*)(dst + 8192), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)aoff[h * 2 + j]), (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
       kua[h] += BK * 2;
-      return;
-    }
-    {
-      const bf16* s0 = (a_cur[h * 2] && kca[h] < kend) ? a_cur[h * 2] + cca[h] : zero;
-      const bf16* s1 = (a_cur[h * 2 + 1] && kca[h] + dkl < kend) ? a_cur[h * 2 + 1] + cca[h] + dkl : zero;
-      __builtin_amdgcn_global_load_lds((p8_gbl_t*)s0, (p8_lds_t*)dst, 16, 0, 0);
-      if constexpr (LAY) __builtin_amdgcn_global_load_lds((p8_gbl_t*)((const char*)s1 - 1024), (p8_lds_t*)dst, 16, 1024, 0);
-      else __builtin_amdgcn_global_load_lds((p8_gbl_t*)s1, (p8_lds_t*)(dst + 8192), 16, 0, 0);
-    }
-    kca[h] += BK;
-    cca[h] += BK;
-    if constexpr (GATHER != GATHER_NONE) {
-      if (cca[h] >= Cin) {                         // next filter tap (uniform across the wave when Cin % 64 == 0)
-        do { cca[h] -= Cin; ++tapa[h]; } while (cca[h] >= Cin);
-        retap(h * 2, tapa[h]);
-        retap(h * 2 + 1, tapa[h]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16* src = (a_cur[h * 2 + j] && kca[h] < kend) ? a_cur[h * 2 + j] + cca[h] : zero;
+        __builtin_amdgcn_global_load_lds((p8_gbl_t*)src, (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
+      }
+      kca[h] += BK;
+      cca[h] += BK;
+      if constexpr (GATHER != GATHER_NONE) {
+        if (cca[h] >= Cin) {                         // next filter tap (uniform across the wave: Cin % 64 == 0)
+          do { cca[h] -= Cin; ++tapa[h]; } while (cca[h] >= Cin);
+          retap(h * 2, tapa[h]);
+          retap(h * 2 + 1, tapa[h]);
+        }
       }
     }
   };
   auto stage_b = [&](auto hc, auto dc) {
     constexpr int h = decltype(hc)::value, d = decltype(dc)::value;
     if ((ABL & 1) && in_loop) return;
-    char* dst = smem + AREA + h * HALF + d * PAR + piece(0) * 1024;
+    char* dst = smem + AREA + h * HALF + d * PAR + wave * 1024;
     if constexpr (FAST) {
       const char* sb = Bb + min(kub[h], kumax);
-      __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)boff[h * 2]), (p8_lds_t*)dst, 16, 0, 0);
-      if constexpr (LAY) __builtin_amdgcn_global_load_lds((p8_gbl_t*)((sb - 1024) + (unsigned long)boff[h * 2 + 1]), (p8_lds_t*)dst, 16, 1024, 0);
-      else __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)boff[h * 2 + 1]), (p8_lds_t*)(dst + 8192), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)boff[h * 2 + j]), (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
       kub[h] += BK * 2;
-      return;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16* src = (b_base[h * 2 + j] && kcb[h] < kend) ? b_base[h * 2 + j] + kcb[h] : zero;
+        __builtin_amdgcn_global_load_lds((p8_gbl_t*)src, (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
+      }
+      kcb[h] += BK;
     }
-    {
-      const bf16* s0 = (b_base[h * 2] && kcb[h] < kend) ? b_base[h * 2] + kcb[h] : zero;
-      const bf16* s1 = (b_base[h * 2 + 1] && kcb[h] + dkl < kend) ? b_base[h * 2 + 1] + kcb[h] + dkl : zero;
-      __builtin_amdgcn_global_load_lds((p8_gbl_t*)s0, (p8_lds_t*)dst, 16, 0, 0);
-      if constexpr (LAY) __builtin_amdgcn_global_load_lds((p8_gbl_t*)((const char*)s1 - 1024), (p8_lds_t*)dst, 16, 1024, 0);
-      else __builtin_amdgcn_global_load_lds((p8_gbl_t*)s1, (p8_lds_t*)(dst + 8192), 16, 0, 0);
-    }
-    kcb[h] += BK;
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -308,22 +305,6 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
-  // SCHED 2: the phase's half-tile DMA is issued INSIDE the matrix segment, the four waves of a group taking turns one K16 step apart (wave wc
-  // after its MFMA 2 wc), so the load segment of the partner group carries fragment reads only and the texture path sees one 1 KiB request per
-  // ~32 cycles instead of a burst of eight
-  auto mma_dma = [&](auto xc, auto yc, bf16x8 (&fb)[4], auto&& dma) {
-    constexpr int x = decltype(xc)::value, y = decltype(yc)::value;
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if constexpr (!(ABL & 4)) acc[x][0][y] = H16<FL>::mfma(fa[0][kk], fb[kk], acc[x][0][y]);
-      if (wc == kk) dma();
-      if constexpr (!(ABL & 4)) acc[x][1][y] = H16<FL>::mfma(fa[1][kk], fb[kk], acc[x][1][y]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
   auto bar = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -333,115 +314,45 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   auto ktile = [&](auto dc) {
     using D = decltype(dc);
     using DX = std::integral_constant<int, D::value ^ 1>;
-    if constexpr (SCHED == 2) {
-      // every half tile of K tile s+2 is issued during K tile s, 1.5 phases after the last read of the buffer it replaces:
-      //   phase 1: read A0[d]    |             barrier | a0 x b0 + DMA B0(s+2) -> B0[d] | barrier      (B0[d] was read in phase 4 of tile s-1)
-      //   phase 2: read B1[d]    |             barrier | a0 x b1 + DMA A0(s+2) -> A0[d] | barrier
-      //   phase 3: read A1[d]    | vmcnt(10) | barrier | a1 x b0 + DMA B1(s+2) -> B1[d] | barrier      (vmcnt(10): B0(s+1) landed)
-      //   phase 4: read B0[d^1]  | vmcnt(6)  | barrier | a1 x b1 + DMA A1(s+2) -> A1[d] | lgkmcnt(0) | barrier   (vmcnt(6): the rest of K tile s+1 landed)
-      // WAR: a DMA issued in the matrix segment of phase q+1 follows this wave's first barrier of q+1, which the lagging group passes as ITS second
-      // barrier of phase q -- after its lgkmcnt(0) retired the reads of phase q.  RAW as before: wait in the load segment of phase q, read in q+1.
-      read_a(I0{}, D{});
-      bar();
-      p8_wait12(fa, fb0);
-      mma_dma(I0{}, I0{}, fb0, [&]() { stage_b(I0{}, D{}); });
-      bar();
-      read_b(I1{}, D{}, fb1);
-      bar();
-      p8_wait4(fb1);
-      mma_dma(I0{}, I1{}, fb1, [&]() { stage_a(I0{}, D{}); });
-      bar();
-      read_a(I1{}, D{});
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      bar();
-      p8_wait8(fa);
-      mma_dma(I1{}, I0{}, fb0, [&]() { stage_b(I1{}, D{}); });
-      bar();
-      read_b(I0{}, DX{}, fb0);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      bar();
-      mma_dma(I1{}, I1{}, fb1, [&]() { stage_a(I1{}, D{}); });
-      p8_wait4(fb0);
-      bar();
-      return;
-    }
-    if constexpr (SCHED == 1) {
-      // phase 1: a0 x b0 (b0 was read in phase 4 of the previous K tile / the prologue)
-      read_a(I0{}, D{});
-      stage_a(I1{}, DX{});
-      bar();
-      p8_wait12(fa, fb0);
-      mma(I0{}, I0{}, fb0);
-      bar();
-      // phase 2: a0 x b1
-      read_b(I1{}, D{}, fb1);
-      stage_b(I0{}, D{});
-      bar();
-      p8_wait4(fb1);
-      mma(I0{}, I1{}, fb1);
-      bar();
-      // phase 3: a1 x b0
-      read_a(I1{}, D{});
-      stage_a(I0{}, D{});
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // B0 of K tile s+1 (issued five phases ago) has landed: read it in phase 4
-      bar();
-      p8_wait8(fa);
-      mma(I1{}, I0{}, fb0);
-      bar();
-      // phase 4: a1 x b1, and b0 of the next K tile
-      read_b(I0{}, DX{}, fb0);
-      stage_b(I1{}, D{});
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // the rest of K tile s+1 has landed
-      bar();
-      mma(I1{}, I1{}, fb1);
-      p8_wait4(fb0);                                        // retired before this phase's second barrier: B0[d^1] may be restaged in phase 2 of the next tile
-      bar();
-      return;
-    }
-    // phase 1
-    read_b(I0{}, D{}, fb0);
-    __builtin_amdgcn_sched_barrier(0);
+    // phase 1: a0 x b0 (b0 was read in phase 4 of the previous K tile / the prologue)
     read_a(I0{}, D{});
     stage_a(I1{}, DX{});
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the four B0 reads (issued first) are done: B0[d] may be restaged in phase 2
     bar();
     p8_wait12(fa, fb0);
     mma(I0{}, I0{}, fb0);
     bar();
-    // phase 2
+    // phase 2: a0 x b1
     read_b(I1{}, D{}, fb1);
     stage_b(I0{}, D{});
     bar();
     p8_wait4(fb1);
     mma(I0{}, I1{}, fb1);
     bar();
-    // phase 3
+    // phase 3: a1 x b0
     read_a(I1{}, D{});
     stage_a(I0{}, D{});
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // B0 of K tile s+1 (issued five phases ago) has landed: read it in phase 4
     bar();
     p8_wait8(fa);
-    mma(I1{}, I1{}, fb1);
-    bar();
-    // phase 4
-    stage_b(I1{}, D{});
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // K tile s+1 has landed (this wave's share); B0 / A0 / B1 of s+2 stay in flight
-    bar();
     mma(I1{}, I0{}, fb0);
+    bar();
+    // phase 4: a1 x b1, and b0 of the next K tile
+    read_b(I0{}, DX{}, fb0);
+    stage_b(I1{}, D{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // the rest of K tile s+1 has landed (this wave's share); B0 / A0 / B1 of s+2 stay in flight
+    bar();
+    mma(I1{}, I1{}, fb1);
+    p8_wait4(fb0);                                        // retired before this phase's second barrier: B0[d^1] may be restaged in phase 2 of the next tile
     bar();
   };
 
   if (nk > 0) {
     stage_b(I0{}, I0{}); stage_a(I0{}, I0{}); stage_b(I1{}, I0{}); stage_a(I1{}, I0{});      // K tile 0
     stage_b(I0{}, I1{}); stage_a(I0{}, I1{}); stage_b(I1{}, I1{});                            // K tile 1 without its A1 half (phase 1 of tile 0)
-    if constexpr (SCHED == 2) {
-      stage_a(I1{}, I1{});                                                                    // ... SCHED 2: the whole of K tile 1
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     bar();
-    if constexpr (SCHED >= 1) read_b(I0{}, I0{}, fb0);
-    if constexpr (SCHED == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // retired before anyone may restage B0[0] (matrix segment of phase 1)
+    read_b(I0{}, I0{}, fb0);
+    p8_wait4(fb0);                                   // retired before the first barrier of the loop: B0[0] is restaged in phase 2 of K tile 0
     if (wr == 1) bar();                              // group 1 runs one barrier behind group 0 from here on
     in_loop = true;
     for (int s = 0; s < nk; s += 2) {
@@ -471,42 +382,33 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
 }
 
 template <int FL>
-static void launch_p8_f(const GemmArgs& a, dim3 grid, int tile, hipStream_t st) {
-  if (tile != 530 && a.gather == GATHER_NONE && a.epi == EPI_PLAIN && a.K % 64 == 0) {   // experimental variants (A/B): 531 = 532 with adjacent DMA pieces (one M0 per half tile), 532 uniform-base DMA + balanced reads, 533 + DMA inside the matrix segment
-    if (tile >= 534) {
-      if (tile == 534) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 1, 1>), grid, dim3(512), 0, st, a);
-      else if (tile == 535) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 1, 2>), grid, dim3(512), 0, st, a);
-      else if (tile == 536) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 1, 3>), grid, dim3(512), 0, st, a);
-      else if (tile == 537) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 1, 4>), grid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 2, 4>), grid, dim3(512), 0, st, a);
-      return;
-    }
-    if (tile == 531) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 1, 0, 1>), grid, dim3(512), 0, st, a);
-    else if (tile == 532) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 1>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN, 1, 2>), grid, dim3(512), 0, st, a);
-    return;
-  }
+static void launch_p8_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  const bool fast = a.gather == GATHER_NONE && a.K % 64 == 0;
+#define DPB_P8(G, E) do { if (fast) hipLaunchKernelGGL((gemm_p8_kernel<G, FL, E, (G == GATHER_NONE)>), grid, dim3(512), 0, st, a); \
+                          else hipLaunchKernelGGL((gemm_p8_kernel<G, FL, E, 0>), grid, dim3(512), 0, st, a); } while (0)
   switch (a.gather) {
     case GATHER_NONE:
-      if (a.epi == EPI_GEGLU_TAN) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_GEGLU_TAN>), grid, dim3(512), 0, st, a);
-      else if (a.epi == EPI_GEGLU_ADJ) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_GEGLU_ADJ>), grid, dim3(512), 0, st, a);
-      else if (a.epi == EPI_GEGLU_FWD) hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_GEGLU_FWD>), grid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((gemm_p8_kernel<GATHER_NONE, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a);
+      if (a.epi == EPI_GEGLU_TAN) DPB_P8(GATHER_NONE, EPI_GEGLU_TAN);
+      else if (a.epi == EPI_GEGLU_ADJ) DPB_P8(GATHER_NONE, EPI_GEGLU_ADJ);
+      else if (a.epi == EPI_GEGLU_FWD) DPB_P8(GATHER_NONE, EPI_GEGLU_FWD);
+      else DPB_P8(GATHER_NONE, EPI_PLAIN);
       break;
-    case GATHER_CONV: hipLaunchKernelGGL((gemm_p8_kernel<GATHER_CONV, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a); break;
-    case GATHER_CONVT: hipLaunchKernelGGL((gemm_p8_kernel<GATHER_CONVT, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL((gemm_p8_kernel<GATHER_UPCONV, FL, EPI_PLAIN>), grid, dim3(512), 0, st, a); break;
+    case GATHER_CONV: DPB_P8(GATHER_CONV, EPI_PLAIN); break;
+    case GATHER_CONVT: DPB_P8(GATHER_CONVT, EPI_PLAIN); break;
+    default: DPB_P8(GATHER_UPCONV, EPI_PLAIN); break;
   }
+#undef DPB_P8
 }
 
 // tile code 530: 256 x 256 x 64, 8 waves, 4 phases per K tile
 int launch_gemm_p8(const GemmArgs& a, int tile, hipStream_t st) {
-  if (tile < 530 || tile > 538) { set_error("gemm: unknown 8-phase tile code %d", tile); return -1; }
+  if (tile != 530) { set_error("gemm: unknown 8-phase tile code %d", tile); return -1; }
   if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ || (a.epi != EPI_PLAIN && a.gather != GATHER_NONE)) { set_error("gemm: the 8-phase tile has the plain and GEGLU epilogues only"); return -1; }
+  if (a.gather != GATHER_NONE && a.Cin % 64) { set_error("gemm: the 8-phase tile gathers whole 64-channel K tiles (Cin = %d)", a.Cin); return -1; }
   const int sk = a.splitk > 1 ? a.splitk : 1;
   const dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256), a.Z1 * a.Z2, sk);
-  if (a.fl) launch_p8_f<1>(a, grid, tile, st);
-  else launch_p8_f<0>(a, grid, tile, st);
+  if (a.fl) launch_p8_f<1>(a, grid, st);
+  else launch_p8_f<0>(a, grid, st);
   DPB_CHECK(hipGetLastError());
   return 0;
 }
