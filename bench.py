@@ -500,7 +500,7 @@ def main():
         kinds = {"gemm_kernel<%s,64,64,4>" % tname: eng.profile_read(0), "gemm_kernel<%s,128,128,4>" % tname: eng.profile_read(1),
                  "gemm_dma_kernel<128,128,3> / <256,128,3>": eng.profile_read(2), "gemm_dma_kernel<64,64,4>": eng.profile_read(3),
                  "gemm_ring64_kernel<128,128,2>": eng.profile_read(4), "conv_halo_kernel": eng.profile_read(5),
-                 "gemm_ring64_kernel<256,256,2> (8 waves)": eng.profile_read(6)}
+                 "gemm_ring64_kernel<256,256,2> (8 waves)": eng.profile_read(6), "gemm_p8_kernel (256x256, 8 waves, 8-phase)": eng.profile_read(11)}
         attn = {"attention forward (flash)": eng.profile_read(7), "attention tangent (attn_jvp_kernel)": eng.profile_read(8),
                 "attention adjoint (query-major + key-major launches)": eng.profile_read(9), "cross-attention tangent / adjoint (attn_cross_kernel)": eng.profile_read(10)}
         ovh_ms = eng.profile_overhead_ms()

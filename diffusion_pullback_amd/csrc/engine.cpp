@@ -175,7 +175,7 @@ int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false) {
   if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl, pend); e->n_launch += nl; e->pend.on = pend && pend->splitk > 1; return r; }
   dpb_engine::Prof p;
   p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
-  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile
+  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm == 530 ? 11 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile, 11: 8-phase 256x256 tile (gemm_p8.hip)
   p.M = a.M; p.N = a.N; p.K = a.K; p.Z = a.Z1 * a.Z2; p.gather = a.gather;
   DPB_CHECK(hipEventCreate(&p.a));
   DPB_CHECK(hipEventCreate(&p.b));
@@ -1312,6 +1312,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_kch")) kch = value;
   else if (!strcmp(key, "gemm_dma_auto")) { gemm_debug_dma_auto(value); return 0; }
   else if (!strcmp(key, "gemm_order")) { gemm_debug_order(value); return 0; }
+  else if (!strcmp(key, "p8")) { gemm_debug_p8(value); return 0; }
   else if (!strcmp(key, "gn_deterministic")) { gn_debug_deterministic(value); return 0; }
   else if (!strcmp(key, "graph_iterate")) { g_graph_iterate = value; return 0; }
   else if (!strcmp(key, "attn_shared")) { attn_debug_shared(value); return 0; }

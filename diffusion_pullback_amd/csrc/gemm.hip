@@ -445,6 +445,8 @@ static int g_force_tile = 0, g_force_splitk = 0, g_kch = 0, g_dma_auto = 1, g_fo
 void gemm_debug_order(int o) { g_force_order = o; }
 void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_force_splitk = splitk; g_kch = kch; }
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
+static int g_p8 = 1;
+void gemm_debug_p8(int on) { g_p8 = on; }
 static thread_local int t_reduce_launched = 0;   // set by launch_t when a splitk_reduce_kernel launch followed the product
 static thread_local GemmArgs* t_pending = nullptr;   // launch_gemm(..., pending): where a deferrable reduction is parked instead of launched
 
@@ -485,12 +487,30 @@ static const ShapeOverride* find_override(const GemmArgs& a) {
   return nullptr;
 }
 
+// The 8-phase 256 x 256 tile (gemm_p8.hip) takes a product when its tiles fill the chip (one 8-wave block per CU): >= 160 tiles; at most 25 % of the
+// tile area padding (N = 320 is 37.5 %: stays on the 128-column rings / the halo kernel -- except plain rows with >= 2048 tiles, where the tile still
+// wins by 3-10 %); the last round of 256 tiles at least 58 % occupied (or >= 4 rounds); K >= 640 (a K = 320 product is five K tiles: prologue and
+// epilogue dominate -- 62 vs 56 us on 20480 x 2560 x 320 -- until >= 4096 tiles amortise them: 850 vs 922 us on 327680 x 2560 x 320).
+// Measured per shape against the round-4 dispatch at 5 / 20 / 80 tangents: profiles/r05_p8_shapes.txt (plain rows +5-25 %; 3x3 convolutions against the
+// halo-tile kernel: N = 1280 +16-19 %, N = 640 +10 % at 20 tangents and equal at 80).
+static int p8_wants(int dtype, const GemmArgs& a) {
+  static const int p8_env = getenv("DPB_P8") ? atoi(getenv("DPB_P8")) : 1;      // tuning switch (0: rings / halo kernel as in round 4)
+  if (!p8_env || !g_p8 || dtype == DT_F32 || a.A2 || !a.zeros || a.Z1 * a.Z2 != 1 || a.K % 8) return 0;
+  if (a.gather != GATHER_NONE && (a.Cin % 64 || a.epi != EPI_PLAIN)) return 0;
+  if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ || (a.epi != EPI_PLAIN && a.N % 256)) return 0;
+  const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), rounds = (t256 + 255) / 256;
+  if (t256 < 160 || (a.K < 640 && !(a.K >= 320 && t256 >= 4096))) return 0;
+  const double fill = (double)a.M * a.N / ((double)t256 * 65536.0);
+  if (fill < ((t256 >= 2048 && a.gather == GATHER_NONE) ? 0.6 : 0.75)) return 0;
+  return t256 >= 1024 || (double)t256 >= 0.58 * 256.0 * (double)rounds;
+}
+
 // the halo-tile 3x3 convolution (gemm_halo.hip): every supported shape of the path measured faster than the implicit-GEMM rings
 int gemm_uses_halo(int dtype, const GemmArgs& a) {
   static const int halo_env = getenv("DPB_CONV_HALO") ? atoi(getenv("DPB_CONV_HALO")) : 1;   // tuning switch (0: implicit-GEMM rings)
   const ShapeOverride* ov = g_force_tile ? nullptr : find_override(a);
   const int force = ov ? ov->code : g_force_tile;
-  const bool want = force == 600 || (halo_env && force == 0 && g_dma_auto);
+  const bool want = force == 600 || (halo_env && force == 0 && g_dma_auto && !p8_wants(dtype, a));
   // (8x8 images, four per tile, are supported but measure no better than the split-K ring: forced only)
   return want && dtype != DT_F32 && conv_halo_supported(a) && (a.H * a.W >= 256 || force == 600);
 }
@@ -517,6 +537,7 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
   // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
+  if (p8_wants(dtype, a)) return 530;
   // 256x256 8-wave tile (half the L2->LDS bytes per flop): plain-row products that give >= 160 such tiles with < 7 % padding and K >= 640
   // -- 12-26 % ahead of the 128x128 ring there, behind it below (profiles/r02_gemm_big_microbench.txt, r02_gemm_split_microbench.txt)
   static const int big_env = getenv("DPB_TILE256") ? atoi(getenv("DPB_TILE256")) : 1;   // tuning switch
@@ -582,7 +603,7 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
     // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
     // profiles/r02_gemm_split_microbench.txt (5120x640: K 1920 / 2560 24 / 32 us unsplit vs 34 / 41 us three-fold, K 5120 52 us two-fold vs
     // 58 unsplit; 1280x3840x1280 25 vs 36 us; 320x10240x1280 18 vs 25 us)
-    if (tile == 518) return 1;                 // one 8-wave block per CU and >= 160 tiles by construction: never split
+    if (tile == 518 || tile == 530) return 1;  // one 8-wave block per CU and >= 160 tiles by construction: never split
     if (tiles >= 192) s = (tiles < 256 && nk >= 128) ? 2 : 1;
     else {
       s = std::max<long>(1, (target + tiles / 2) / tiles);

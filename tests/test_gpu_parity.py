@@ -206,7 +206,7 @@ def test_dma_gemm_bitwise_equals_register_gemm():
                         got = run()
                         for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
                             assert torch.equal(a, b), f"case {(H, cin, cout, ks, stride, pad)} kernel {code} splitk {sk} {name} rep {rep}: max |d| = {(a - b).abs().max().item():.3e}"
-                for code in (512, 513, 514, 515, 516, 517, 518, 521, 522, 523):   # BK=64 rings (gemm_ring64.hip): 128x128 S3, 256x128 S3, 128x128 S4 / S2, 8-wave 256x128 S3 / S2, 8-wave 256x256, half tiles 64x128 S3 / S2, 128x64 S3 (the last four: plain rows only)
+                for code in (512, 513, 514, 515, 516, 517, 518, 521, 522, 523, 530):   # (530: the 8-phase tile, gemm_p8.hip -- gathers with Cin % 64 == 0, else the dispatch substitutes 515) BK=64 rings (gemm_ring64.hip): 128x128 S3, 256x128 S3, 128x128 S4 / S2, 8-wave 256x128 S3 / S2, 8-wave 256x256, half tiles 64x128 S3 / S2, 128x64 S3 (the last four: plain rows only)
                     L.check(lib.dpb_debug_set(b"gemm_tile", code))
                     for rep in range(3):
                         got = run()
@@ -253,6 +253,93 @@ def test_large_plain_row_products_on_the_256_tile_match_the_128_tile():
             del e
     finally:
         L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
+
+
+def test_p8_gemm_bitwise_equals_ring_gemm_and_race_screen():
+    """The 8-phase 256x256 tile (gemm_p8.hip, code 530) issues the same K16 MFMA sequence per output element as the BK = 64 ring (515): primal / tangent /
+    adjoint products must agree BIT FOR BIT -- plain rows (uniform-base DMA addressing), K % 64 != 0 (zero-page K tail), odd and even K-tile counts,
+    ragged M / N, 3x3 / strided / transposed gathers, f16.  Its staging buffers are ordered by counted vmcnt + barriers only (a misplaced read passes
+    whenever the DMA happens to land first), so three sizes are repeated 25 times each against the first run as a race screen."""
+    from diffusion_pullback_amd import lib as L
+    from diffusion_pullback_amd.engine import Engine
+    from diffusion_pullback_amd.tape import Tape
+    lib = L.load()
+    g = torch.Generator().manual_seed(7)
+
+    def engine(H, cin, cout, ks, stride, dtype, batch):
+        p = {"c.weight": torch.randn(cout, cin, ks, ks, generator=g) * 0.05, "c.bias": torch.randn(cout, generator=g)}
+        t = Tape(p, dtype, _dev())
+        t.temb_in = t.buf(1, 8, L.BUF_SHARED)
+        t.x = t.buf(H * H, cin)
+        o = t.conv("c", t.x, (H, H), cout, ks=ks, stride=stride, pad=ks // 2)
+        Ho = int(round(t.buffers[o][0] ** 0.5))
+        t.tap("o", o, cout, Ho, Ho)
+        return Engine(t, 8, False, True, cin, max_batch=batch, max_tangents=batch), Ho
+
+    # (H, cin, cout, ks, stride, batch): K = 64 (one K tile), 128, 192 (odd), 200 (K tail), 1280 ...; M = 256 .. 20480; N = 96 .. 2560
+    cases = [(16, 64, 256, 1, 1, 1), (16, 128, 256, 1, 1, 1), (16, 192, 320, 1, 1, 3), (12, 200, 200, 1, 1, 3), (8, 1280, 1280, 1, 1, 5), (32, 640, 1920, 1, 1, 5),
+             (64, 320, 320, 1, 1, 5), (16, 320, 320, 3, 1, 5), (32, 64, 96, 3, 2, 2), (16, 128, 200, 3, 1, 2), (32, 640, 640, 3, 1, 2)]
+    try:
+        for dtype in (torch.bfloat16, torch.float16):
+            for (H, cin, cout, ks, stride, batch) in (cases if dtype == torch.bfloat16 else cases[2:9:3]):
+                e, Ho = engine(H, cin, cout, ks, stride, dtype, batch)
+                x = torch.randn(batch, cin, H, H, generator=g).cuda()
+                V = torch.randn(batch, cin * H * H, generator=g).cuda()
+                U = torch.randn(batch, cout * Ho * Ho, generator=g).cuda()
+
+                def run():
+                    e.primal(x, 1.0, None, "o")
+                    return e.read("o").clone(), e.jvp("o", V).clone(), e.vjp("o", U).clone()
+                for sk in (1, 2):
+                    L.check(lib.dpb_debug_set(b"gemm_splitk", sk))
+                    L.check(lib.dpb_debug_set(b"gemm_tile", 515)); ref = run()
+                    L.check(lib.dpb_debug_set(b"gemm_tile", 530)); got = run()
+                    for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
+                        assert torch.isfinite(b).all() and torch.equal(a, b), f"{dtype} case {(H, cin, cout, ks, stride, batch)} splitk {sk} {name}: max |d| = {(a - b).abs().max().item():.3e}"
+                del e
+        for (H, cin, cout, ks, batch) in [(16, 256, 256, 1, 1), (16, 512, 512, 1, 2), (64, 2560, 2560, 1, 1), (32, 640, 640, 3, 5)]:
+            e, _ = engine(H, cin, cout, ks, 1, torch.bfloat16, batch)
+            x = torch.randn(batch, cin, H, H, generator=g).cuda()
+            L.check(lib.dpb_debug_set(b"gemm_splitk", 1)); L.check(lib.dpb_debug_set(b"gemm_tile", 530))
+            e.primal(x, 1.0, None, "o")
+            first = e.read("o").clone()
+            for rep in range(25):
+                e.primal(x, 1.0, None, "o")
+                assert torch.equal(e.read("o"), first), f"run {rep} of {(H, cin, cout, ks, batch)} differs from the first: a staging race"
+            del e
+    finally:
+        L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_p8_dispatch_is_bitwise_the_ring_dispatch_on_a_network(dtype):
+    """Inside a network (two-level SD-shaped U-Net, 64 x 64 latents, 5 tangents) the dispatch sends the FF-in / FF-out products of the 32 x 32 level --
+    with the fused GEGLU tangent / adjoint epilogues -- and the other >= 160-tile plain products to the 8-phase tile; with dpb_debug_set("p8", 0) they
+    run on the BK = 64 rings as in round 4.  Same MFMA order, same epilogue code: features, tangents and cotangents must be bitwise equal."""
+    from diffusion_pullback_amd import PullbackUNet, lib as L
+    from oracle import unet_sd
+    lib = L.load()
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=64, ctx_len=77)
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(1, 4, 64, 64, generator=g); ctx = torch.randn(1, 77, 768, generator=g)
+    V = torch.randn(5, 4 * 64 * 64, generator=g).cuda(); U = torch.randn(5, 640 * 32 * 32, generator=g).cuda()
+    tap = ("mid", 0)
+    net = PullbackUNet("sd", cfg, p, dtype=dtype, device=_dev(), max_batch=1, max_rank=5, upto=tap, verbose=False)
+    out = {}
+    try:
+        for on in (1, 0):
+            L.check(lib.dpb_debug_set(b"p8", on))
+            net.engine.profile(True)
+            net.engine.primal(z, 696.2727, ctx, tap)
+            out[on] = (net.engine.read(tap).clone(), net.engine.jvp(tap, V).clone(), net.engine.vjp(tap, U).clone(), net.engine.profile_read(11)[0])
+            net.engine.profile(False)
+    finally:
+        L.check(lib.dpb_debug_set(b"p8", 1))
+    assert out[1][3] >= 2 and out[0][3] == 0, (out[1][3], out[0][3])          # the 8-phase tile really ran (and did not with the switch off)
+    for a, b, name in zip(out[1][:3], out[0][:3], ("features", "jvp", "vjp")):
+        assert torch.equal(a, b), f"{name}: max |d| = {(a - b).abs().max().item():.3e}"
 
 
 def test_batched_samples_match_single_sample_runs():

@@ -164,7 +164,7 @@ def test_sd_model_id_selects_architecture(tmp_path):
 def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
     """dpb_debug_gemm_plan (host-only) over the products of the SD-1.5 / SD-2.1 pullback path at k = 1..10 and 1..8 samples advanced together:
     every plan's split count fits the fp32 slab scratch (a rule once returned before the capacity clamp: 10240 x 1280 x 5120 split two-fold
-    wrote 105 MB of partials into 64 MB), the 256x256 tile is never split and only takes products it tiles with < 7 % padding, fused GEGLU
+    wrote 105 MB of partials into 64 MB), the 256x256 tiles are never split and only take products they tile with < 7 % (ring) / <= 25 % (8-phase) padding, fused GEGLU
     epilogues only go to kernels that implement them, fp32 never leaves the register-staged kernel."""
     import ctypes as C
     from diffusion_pullback_amd import lib as L
@@ -177,7 +177,7 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
         return k.value, t.value, s.value
 
     chans = (320, 640, 960, 1280, 1920, 2560, 3840, 5120, 10240)
-    n_plans = 0
+    n_plans = n_p8 = 0
     for nt in (1, 3, 5, 10, 20, 40, 80):
         for hw in (8, 16, 32, 64):
             M = nt * hw * hw
@@ -192,6 +192,12 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
                         if tile == 518:
                             t256 = -(-M // 256) * -(-N // 256)
                             assert s == 1 and K >= 640 and t256 >= 160 and t256 * 65536 <= 1.07 * M * N, (M, N, K, s)
+                        if tile == 530:                                   # 8-phase tile: fills the chip, <= 25 % padding (40 % from 2048 tiles on), last round >= 58 % occupied, unsplit
+                            t256 = -(-M // 256) * -(-N // 256)
+                            assert dt != L.DPB_F32 and s == 1 and t256 >= 160 and (K >= 640 or (K >= 320 and t256 >= 4096)), (M, N, K, s)
+                            assert (0.6 if t256 >= 2048 else 0.75) * t256 * 65536 <= M * N, (M, N, K, t256)
+                            assert t256 >= 1024 or t256 >= 0.58 * 256 * -(-t256 // 256), (M, N, K, t256)
+                            n_p8 += 1
             for cin in (320, 640, 1280, 1920, 2560):          # 3x3 convolutions of the ResBlocks
                 for cout in (320, 640, 1280):
                     kind, tile, s = plan(L.DPB_BF16, M, cout, 9 * cin, hw, cin)
@@ -200,15 +206,20 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
                     assert kind in (2, 3), (M, cout, cin, kind)           # bf16 convolutions of these sizes: ring or halo-tile kernel
                     if kind == 3:
                         assert hw >= 16 and s <= cin // 64
-    assert n_plans > 4000
+                    if tile == 530:                                       # the 8-phase tile as an implicit-GEMM convolution: whole 64-channel K tiles
+                        assert cin % 64 == 0 and s == 1 and M * cout >= 0.75 * (-(-M // 256) * -(-cout // 256)) * 65536
+                        n_p8 += 1
+    assert n_plans > 4000 and n_p8 > 100
     # the launch that overflowed: now the 256x256 tile, unsplit; and the same product forced onto the 128x128 ring keeps within the scratch
-    assert plan(L.DPB_BF16, 10240, 1280, 5120) == (2, 518, 1)
+    assert plan(L.DPB_BF16, 10240, 1280, 5120) == (2, 530, 1)
+    assert plan(L.DPB_BF16, 20480, 320, 2880, 64, 320)[0] == 3            # N = 320 (37.5 % padding on 256-column tiles): the halo-tile kernel keeps the 64x64-level convolutions
+    assert plan(L.DPB_BF16, 40960, 640, 5760, 32, 640)[:2] == (2, 530)     # many samples advanced together: the 8-phase tile takes the 3x3 convolutions
     # fused GEGLU epilogues: FF-in tangent (N = 2F interleaved) and FF-out adjoint (N = F) of every level go to ring kernels, unsplit
     for M, F, Cc in ((20480, 1280, 320), (5120, 2560, 640), (1280, 5120, 1280), (40960, 2560, 640), (2560, 5120, 1280)):
         for epi, N, K in ((1, 2 * F, Cc), (2, F, Cc)):
             kind, tile, s = plan(L.DPB_BF16, M, N, K, epi=epi)
-            assert kind == 2 and s == 1 and (tile in (128, 130, 132, 256, 518) or 512 <= tile <= 517), (M, N, K, epi, kind, tile, s)
-            if tile == 518:
+            assert kind == 2 and s == 1 and (tile in (128, 130, 132, 256, 518, 530) or 512 <= tile <= 517), (M, N, K, epi, kind, tile, s)
+            if tile in (518, 530):
                 assert N % 256 == 0
 
 
@@ -243,7 +254,7 @@ def test_gemm_override_environment_changes_the_plan_of_the_named_shape_only():
     forced = run("320x1280x1280:0=515/4,10240x1280x5120:0=515/2")
     assert base[0] == [2, 64, 1] and forced[0] == [2, 515, 4]            # the named shape: 64x64 ring unsplit -> BK=64 ring, four-fold
     assert forced[1] == base[1]                                            # an unnamed shape keeps its plan
-    assert base[2] == [2, 518, 1] and forced[2] == [2, 515, 1]             # 2 x 52 MB of slabs do not fit 64 MB: the forced split is clamped to 1
+    assert base[2] == [2, 530, 1] and forced[2] == [2, 515, 1]             # 2 x 52 MB of slabs do not fit 64 MB: the forced split is clamped to 1
     assert forced[3][2] == 1                                               # and with 1 MB of scratch nothing splits
 
 

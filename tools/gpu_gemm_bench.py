@@ -33,7 +33,7 @@ def run(name, H, cin, cout, ks, batch, dtype=torch.bfloat16, variants=((0, 0, 4)
         e.profile(True)
         for _ in range(10):
             e.primal(x, 1.0, None, "o")
-        msb = sum(e.profile_read(kind)[1] for kind in (0, 1, 2, 3, 4, 5, 6)); mss = 0.0
+        msb = sum(e.profile_read(kind)[1] for kind in (0, 1, 2, 3, 4, 5, 6, 11)); mss = 0.0
         e.profile(False)
         ms = (msb + mss) / 10
         torch.cuda.synchronize(); t0 = time.perf_counter()
