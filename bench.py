@@ -168,6 +168,23 @@ def pmc_traffic(dom, enabled):
                   "re-run tools/pmc_mfma.sh + tools/collect_profiles.py after the last kernel change")
 
 
+def trace_time_by_kind(enabled):
+    """Kernel time per power iteration of every GEMM kernel kind from the committed rocprofv3 kernel trace of THIS build (tools/collect_profiles.py
+    stores it next to the PMC traffic, under the same source-hash rule); None when no trace of this build is committed."""
+    if not enabled:
+        return None, "no kernel trace is committed for this workload"
+    from diffusion_pullback_amd import lib as L
+    cur = L._built_hash()
+    for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_sd15_mid_k5_bf16.json")), reverse=True):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+        except (OSError, ValueError):
+            continue
+        if d.get("_src_hash") == cur and d.get("_trace"):
+            return d["_trace"]["by_kind"], f"rocprofv3 --kernel-trace --stats, {d['_trace']['source']} (same source hash {cur[:12]} as the running libdpb.so)"
+    return None, f"null: no committed kernel trace was collected on this build ({cur[:12]}): the fraction falls back to the raw HIP-event figure"
+
+
 def pmc_step_bytes(enabled):
     """HBM bytes of ONE whole power iteration summed over every kernel of the committed PMC passes (same source-hash rule as pmc_traffic)."""
     if not enabled:
@@ -504,34 +521,47 @@ def main():
         attn = {"attention forward (flash)": eng.profile_read(7), "attention tangent (attn_jvp_kernel)": eng.profile_read(8),
                 "attention adjoint (query-major + key-major launches)": eng.profile_read(9), "cross-attention tangent / adjoint (attn_cross_kernel)": eng.profile_read(10)}
         ovh_ms = eng.profile_overhead_ms()
+        KIND_OF = dict(zip(kinds, (0, 1, 2, 3, 4, 5, 6, 11)))
+        ATTN_OF = dict(zip(attn, (7, 8, 9, 10)))
+        raw_ms = {n: eng.profile_read(1000 + c)[1] for n, c in list(KIND_OF.items()) + list(ATTN_OF.items())}   # unclamped raw bracket sums (kind + 1000)
         eng.profile(False)
         dom = max(kinds, key=lambda n: kinds[n][1])                      # dominant = most GPU time
         n_d, ms_c, fl_d = kinds[dom]                                     # ms_c: bracket times minus the calibrated empty bracket
-        ms_d = ms_c + n_d * ovh_ms                                       # RAW event time: what the headline fraction is computed from
+        ms_d = raw_ms[dom]                                               # RAW event time (unclamped bracket sum): what the event-based fraction is computed from
         ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
         ach_corr = fl_d / (ms_c * 1e-3) / 1e12 if ms_c > 0 else 0.0
         mac = MAC_G.get(a.workload) if tap == ("mid", 0) else None
         gemm_ms = sum(v[1] for v in kinds.values())
         headline_cfg = a.workload == "sd15" and dname == "bf16" and S == 1 and k == 5 and tap == ("mid", 0)
         traffic, tnote = pmc_traffic(dom, headline_cfg)
+        trace, trnote = trace_time_by_kind(headline_cfg)
+        tr = trace.get(str(KIND_OF[dom])) if trace else None
+        if tr and tr["ms_per_iter"] > 0:                                 # time from the hash-matched kernel trace, algorithmic flops from this run's launches
+            ach_tr = fl_d / (tr["ms_per_iter"] * 1e-3) / 1e12
+            frac_main, frac_src = ach_tr / PEAK[dname], "rocprofv3 kernel trace (hash-matched profiles/): " + trnote
+        else:
+            ach_tr, frac_main, frac_src = None, ach / PEAK[dname], "raw HIP events of this run (" + trnote + ")"
         step_bytes, snote = pmc_step_bytes(headline_cfg)
         ms_step = 1e3 * dt / (steps if not strong else max(1, len(mine) * ITERS_PER_SAMPLE))
-        raw = lambda v: v[1] + v[0] * ovh_ms
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach / PEAK[dname],
+        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach_tr if ach_tr is not None else ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": frac_main,
+                           "frac_source": frac_src, "achieved_events_raw": ach, "frac_events_raw": ach / PEAK[dname],
+                           "trace_ms_per_iteration": tr["ms_per_iter"] if tr else None, "trace_launches_per_iteration": tr["launches_per_iter"] if tr else None,
                            "traffic": traffic, "traffic_note": tnote,
                            "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
                            "event_bracket_overhead_us": 1e3 * ovh_ms,
                            "achieved_bracket_corrected": ach_corr, "frac_bracket_corrected": ach_corr / PEAK[dname],
                            "avg_launch_us_bracket_corrected": 1e3 * ms_c / max(n_d, 1),
-                           "timing_note": "HIP events around every launch on the engine stream.  `achieved` / `frac` are the RAW event figures (flops / sum of bracket "
+                           "timing_note": "`achieved` / `frac`: algorithmic flops of the dominant kernel kind's launches (this run) over its kernel time per iteration in the "
+                                          "committed rocprofv3 kernel trace when that trace was taken on this build (frac_source says which); otherwise, and always in "
+                                          "`*_events_raw`, HIP events around every launch on the engine stream (flops / sum of raw bracket "
                                           "times); `*_bracket_corrected` subtract a calibrated empty-bracket time per launch (event_bracket_overhead_us) and sit closer "
                                           "to the rocprofv3 kernel trace under profiles/, which lies between the two",
-                           "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * raw(v) / max(v[0], 1),
-                                                    "achieved": v[2] / (raw(v) * 1e-3) / 1e12 if v[0] > 0 else 0.0,
+                           "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * raw_ms[n] / max(v[0], 1),
+                                                    "achieved": v[2] / (raw_ms[n] * 1e-3) / 1e12 if v[0] > 0 else 0.0,
                                                     "achieved_bracket_corrected": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},
-                           "attention_kernels": {n: {"brackets": v[0], "avg_bracket_us": 1e3 * raw(v) / max(v[0], 1), "algorithmic_flops": v[2],
-                                                     "achieved": v[2] / (raw(v) * 1e-3) / 1e12 if v[0] > 0 else 0.0,
-                                                     "frac": v[2] / (raw(v) * 1e-3) / 1e12 / PEAK[dname] if v[0] > 0 else 0.0} for n, v in attn.items()},
+                           "attention_kernels": {n: {"brackets": v[0], "avg_bracket_us": 1e3 * raw_ms[n] / max(v[0], 1), "algorithmic_flops": v[2],
+                                                     "achieved": v[2] / (raw_ms[n] * 1e-3) / 1e12 if v[0] > 0 else 0.0,
+                                                     "frac": v[2] / (raw_ms[n] * 1e-3) / 1e12 / PEAK[dname] if v[0] > 0 else 0.0} for n, v in attn.items()},
                            "attention_flops_note": "algorithmic L x L x d products per head: forward 2, tangent 5 per tangent, adjoint 7 per cotangent, cross-attention 2 "
                                                    "(L x 77 x d); the shared-probability kernels do fewer MFMAs than that (P computed once per sample)",
                            "whole_step_hbm_bytes": step_bytes, "whole_step_hbm_frac": (step_bytes / (ms_step * 1e-3) / 8e12) if step_bytes else None,

@@ -149,7 +149,8 @@ int prof_open(dpb_engine* e, double flops, int kind, int M, int N, int K, int Z,
   if (!e->profiling) return -1;
   dpb_engine::Prof p;
   p.flops = flops; p.big = kind; p.M = M; p.N = N; p.K = K; p.Z = Z; p.gather = gather;
-  if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+  if (hipEventCreate(&p.a) != hipSuccess) return -1;
+  if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return -1; }
   (void)hipEventRecord(p.a, e->stream);
   e->prof.push_back(p);
   return (int)e->prof.size() - 1;
@@ -251,7 +252,7 @@ int conv_fwd(dpb_engine* e, const Op& op, int mode, int n) {
       return gemm(e, f);
     }
   }
-  if (mode == 0 && e->fwd_only && op.geglu_next >= 0 && g_geglu_fwd && !shared_out) {
+  if (mode == 0 && e->fwd_only && op.geglu_next >= 0 && g_geglu_fwd && !shared_out && d.out != e->cur_tap) {   // (a pass that stops AT h needs h written)
     // forward only (dpb_forward): an FF-in product that runs unsplit anyway applies GEGLU in its epilogue -- h [rows][2F] is neither written nor
     // re-read (84 MB per 64x64-level layer at batch 2), one launch less; bitwise the separate product + GEGLU kernel
     const dpb_op_desc& gd = e->ops[op.geglu_next].d;
@@ -1128,7 +1129,12 @@ static int vjp_pass(dpb_engine* e, int tap, const float* U, int nt, float* W) {
   if (!e->ginit[e->x_buf]) return fail("tap buffer %d is not connected to x", tap);
   const Buf& bx = e->bufs[e->x_buf];
   e->n_launch++;
-  return launch_nhwc_to_nchw(e->dtype, e->G(e->x_buf), W, nt, e->x_channels, bx.rows, bx.C, e->stream);
+  const int r = launch_nhwc_to_nchw(e->dtype, e->G(e->x_buf), W, nt, e->x_channels, bx.rows, bx.C, e->stream);
+  // Invariant of Buf::g_off / t_off: between passes every buffer's cotangent storage is its own (g_off == g_off0).  Inside the pass the residual adjoint
+  // swaps g_off between buffers and U == nullptr lends the tap's TANGENT storage to its cotangent; undo both here so that nothing that reads G() or
+  // T(tap) after the pass (a debug read, a later feature) sees aliased data.  (The launch above is already enqueued with the pointer it needs.)
+  for (auto& b : e->bufs) b.g_off = b.g_off0;
+  return r;
 }
 
 int dpb_vjp(dpb_engine* e, int tap, const float* U, int nt, float* W) {
@@ -1288,11 +1294,13 @@ int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double*
   if (!e || !count || !total_ms || !flops) return fail("null argument");
   DPB_CHECK(hipStreamSynchronize(e->stream));
   *count = 0; *total_ms = 0; *flops = 0;
+  const bool raw = big_tile >= 1000;                 // kind + 1000: the RAW bracket times (no empty-bracket correction, nothing clamped)
+  if (raw) big_tile -= 1000;
   for (auto& p : e->prof) {
     if (p.big != big_tile) continue;
     float ms = 0;
     DPB_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
-    ms = ms > e->prof_overhead_ms ? ms - e->prof_overhead_ms : 0.f;
+    if (!raw) ms = ms > e->prof_overhead_ms ? ms - e->prof_overhead_ms : 0.f;
     *count += 1; *total_ms += ms; *flops += p.flops;
   }
   return 0;

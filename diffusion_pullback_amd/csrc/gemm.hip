@@ -502,6 +502,9 @@ static int p8_wants(int dtype, const GemmArgs& a) {
   if (t256 < 160 || (a.K < 640 && !(a.K >= 320 && t256 >= 4096))) return 0;
   const double fill = (double)a.M * a.N / ((double)t256 * 65536.0);
   if (fill < ((t256 >= 2048 && a.gather == GATHER_NONE) ? 0.6 : 0.75)) return 0;
+  // N = 640 convolutions (17 % padding): ahead of the halo-tile kernel at 20 tangents (157 vs 173 us), behind it at 80 -- inside the configs[3] pass
+  // 686 / 736 us against 644 / 692 (profiles/r05_roofline_sd15_mid_k10x8_bf16.md, first run): the halo kernel keeps them from 512 tiles on
+  if (a.gather != GATHER_NONE && fill < 0.9 && t256 > 512) return 0;
   return t256 >= 1024 || (double)t256 >= 0.58 * 256.0 * (double)rounds;
 }
 

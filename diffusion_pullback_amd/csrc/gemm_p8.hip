@@ -369,12 +369,86 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   // at columns n0 + (wave & 1) * 64 of its n0: hand it the 128-column pair base of this wave.
   float* stg = reinterpret_cast<float*>(smem) + wave * 32 * SLD;
   const int n0w = n0 + (wc >> 1) * 128;
-  static_for<0, 4>([&](auto ic) {
+  auto stage_acc = [&](auto ic) {
     constexpr int x = decltype(ic)::value >> 1, i = decltype(ic)::value & 1;
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SLD + y * 32 + l31] = acc[x][i][y][r];
+  };
+  if constexpr (EPI == EPI_PLAIN) {
+    if (p.splitk <= 1 && p.vec_ok && !(p.N & 7)) {
+      // The common epilogue (alpha, bias, row bias, residual, accumulate; 16-byte stores), with one resident block per CU: a wave stages and re-reads
+      // only ITS OWN 32 x 64 slab, so the four slab rounds need no block barrier (LDS executes a wave's instructions in order), and the operands of
+      // round r+1 -- which do not depend on the product -- are loaded while round r is staged and stored: one exposed memory round trip per wave
+      // instead of four (K = 640 products spent a third of their time here).  Same additions in the same order as epilogue_slab: bitwise equal.
+      const int c8 = lane & 7, r0 = lane >> 3, n = n0w + (wave & 1) * WN + c8 * 8;
+      const bool act = n < p.N;                       // (the lane still STAGES its accumulators: other lanes read them)
+      {
+        float b8[8];
+        if (p.bias && act) { Vec<float>::load(p.bias + n, b8); Vec<float>::load(p.bias + n + 4, b8 + 4); }
+        struct Ops { uint4 rr[4], ro[4], rb[4]; } ops[2];
+        auto load_ops = [&](int round, Ops& o) {
+          const int mrow0 = m0 + wr * 128 + (round >> 1) * 64 + (round & 1) * 32;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int mc = min(mrow0 + u * 8 + r0, p.M - 1);
+            if (!act) continue;
+            if (R) o.rr[u] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + n);
+            if (p.accumulate) o.ro[u] = *reinterpret_cast<const uint4*>(C + (long)mc * p.ldc + n);
+            if (p.rowbias) o.rb[u] = *reinterpret_cast<const uint4*>((const bf16*)p.rowbias + (long)((mc / p.rows_per_sample) / p.rowbias_div) * p.N + n);
+          }
+        };
+        load_ops(0, ops[0]);
+        static_for<0, 4>([&](auto ic) {
+          constexpr int round = decltype(ic)::value;
+          if constexpr (round + 1 < 4) load_ops(round + 1, ops[(round + 1) & 1]);
+          stage_acc(ic);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const Ops& o = ops[round & 1];
+          const int mrow0 = m0 + wr * 128 + (round >> 1) * 64 + (round & 1) * 32;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = u * 8 + r0, m = mrow0 + row;
+            float v[8], t8[8];
+            Vec<float>::load(stg + row * SLD + c8 * 8, v);
+            Vec<float>::load(stg + row * SLD + c8 * 8 + 4, v + 4);
+            if (m >= p.M || !act) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+            if (p.bias) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += b8[e];
+            }
+            if (p.rowbias) {
+              H16<FL>::load8(reinterpret_cast<const bf16*>(&o.rb[u]), t8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += t8[e];
+            }
+            if (R) {
+              H16<FL>::load8(reinterpret_cast<const bf16*>(&o.rr[u]), t8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += t8[e];
+            }
+            if (p.accumulate) {
+              H16<FL>::load8(reinterpret_cast<const bf16*>(&o.ro[u]), t8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += t8[e];
+            }
+            H16<FL>::store8(C + (long)m * p.ldc + n, v);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is re-staged by the next round: keep its reads ahead of those writes
+          __builtin_amdgcn_wave_barrier();
+        });
+      }
+      return;
+    }
+  }
+  static_for<0, 4>([&](auto ic) {
+    constexpr int x = decltype(ic)::value >> 1, i = decltype(ic)::value & 1;
+    stage_acc(ic);
     __syncthreads();
     epilogue_slab<FL, WN, SLD, EPI>(p, C, R, reinterpret_cast<const float*>(smem), wave, lane, m0 + wr * 128 + x * 64 + i * 32, n0w, (long)ksplit * gridDim.y + zb);
     __syncthreads();

@@ -289,8 +289,9 @@ class EditStableDiffusion(_EditBase):
         return results
 
     def _edit_trajectories_together(self, idx, op, block_idx, vis_num, vis_num_pc, vT, original_zt, lat_shape):
-        """The loop body of edit.py:276-307 for all pending (pc, +-) experiments at once (self.trajectory_batch > 1): same experiments, names, skips and
-        results; the n chains of x-space guidance take ONE U-Net call of batch 2 n per step ([z_1..z_n | z_1 + s v_1 .. z_n + s v_n]) and the n * (vis_num + 1)
+        """The loop body of edit.py:276-307 for all pending (pc, +-) experiments at once (self.trajectory_batch > 1): same experiments, names and skips;
+        results equal to the sequential path up to 16-bit rounding (the GEMM tile / split-K selection depends on batch x rows, so a batch-2n call sums
+        in another order than n batch-2 calls: fp32 engines agree to 2e-3, bf16 to a few 1e-2 over the chained steps -- tests/test_gpu_edit.py); the n chains of x-space guidance take ONE U-Net call of batch 2 n per step ([z_1..z_n | z_1 + s v_1 .. z_n + s v_n]) and the n * (vis_num + 1)
         decode trajectories ONE call of that batch per DDIM step (further split only by the engine's batch limit)."""
         todo = []
         for pc_idx in range(vis_num_pc):

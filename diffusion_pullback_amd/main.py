@@ -57,7 +57,8 @@ _FLAGS = [  # (name, type, default) -- define_argparser.py:20-110, live path onl
     ("net_scale", str, "full"), ("vae", str, "none"), ("text_encoder", str, "none"), ("tokenizer_dir", str, ""),
     ("timing", str2bool, False),      # wall-clock breakdown of the run by phase (timing.py; synchronises at phase boundaries)
     # U-Net batch of the edit trajectories: the 2 * vis_num_pc independent (pc, +-) edits of edit.py:276-307 run together (x-space guidance as one batch-2n call per
-    # step, the n * (vis_num + 1) decode trajectories as one batch).  Same files and tensors; 0 / 1 = one experiment after another, memory_bound latents per call
+    # step, the n * (vis_num + 1) decode trajectories as one batch).  Same files, tensors equal up to 16-bit rounding (tile / split-K choices depend on the batch);
+    # 0 / 1 = one experiment after another, memory_bound latents per call (the setting for bitwise-reproducible runs); an explicit --memory_bound caps it
     ("trajectory_batch", int, 20),
 ]
 
@@ -68,6 +69,11 @@ def parse_args(argv=None):
         p.add_argument("--" + name, type=typ, default=default, required=False)
     p.add_argument("--note", type=str, required=True)
     args, extra = p.parse_known_args(argv)
+    # an explicitly given --memory_bound also bounds the trajectory batching below (the reference then resets memory_bound itself to its per-model
+    # constant, define_argparser.py:211-221 -- kept in preset() -- but a user who passed a bound to fit memory must not get 20 latents per call)
+    import sys as _sys
+    given = [a for a in (argv if argv is not None else _sys.argv[1:]) if a == "--memory_bound" or a.startswith("--memory_bound=")]
+    args.memory_bound_given = args.memory_bound if given else 0
     if extra:
         print(f"note: ignoring flags of experiments outside the pullback path: {extra}")
     return args
@@ -102,6 +108,8 @@ def preset(args):
     args.dtype = torch.float32                      # boundary dtype of latents
     if args.use_x_space_guidance:
         args.x_space_guidance_scale = X_SPACE_GUIDANCE_SCALE_DICT["stable-diffusion" if args.is_stable_diffusion else "uncond"][args.h_t]
+    if getattr(args, "memory_bound_given", 0) > 0:
+        args.trajectory_batch = min(args.trajectory_batch, args.memory_bound_given)
     if args.is_stable_diffusion:
         args.c_in, args.image_size, args.memory_bound = 4, 64, 5
         assert args.use_yh_custom_scheduler

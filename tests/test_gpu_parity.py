@@ -266,12 +266,13 @@ def test_p8_gemm_bitwise_equals_ring_gemm_and_race_screen():
     lib = L.load()
     g = torch.Generator().manual_seed(7)
 
-    def engine(H, cin, cout, ks, stride, dtype, batch):
+    def engine(H, cin, cout, ks, stride, dtype, batch, res=False):
         p = {"c.weight": torch.randn(cout, cin, ks, ks, generator=g) * 0.05, "c.bias": torch.randn(cout, generator=g)}
         t = Tape(p, dtype, _dev())
         t.temb_in = t.buf(1, 8, L.BUF_SHARED)
         t.x = t.buf(H * H, cin)
-        o = t.conv("c", t.x, (H, H), cout, ks=ks, stride=stride, pad=ks // 2)
+        o = t.conv("c", t.x, (H, H), cout, ks=ks, stride=stride, pad=ks // 2, res=t.x if res else -1)   # res: y = W x + b + x (residual read in the epilogue;
+        #                                                                                                 the adjoint then ACCUMULATES W^T g onto the skip path's g)
         Ho = int(round(t.buffers[o][0] ** 0.5))
         t.tap("o", o, cout, Ho, Ho)
         return Engine(t, 8, False, True, cin, max_batch=batch, max_tangents=batch), Ho
@@ -297,6 +298,20 @@ def test_p8_gemm_bitwise_equals_ring_gemm_and_race_screen():
                     for a, b, name in zip(ref, got, ("primal", "jvp", "vjp")):
                         assert torch.isfinite(b).all() and torch.equal(a, b), f"{dtype} case {(H, cin, cout, ks, stride, batch)} splitk {sk} {name}: max |d| = {(a - b).abs().max().item():.3e}"
                 del e
+        # residual + accumulate epilogue operands (prefetched one slab round ahead by the 8-phase tile's own epilogue), ragged M
+        for (H, c, batch) in [(32, 640, 20), (20, 320, 3), (16, 1280, 7)]:
+            e, Ho = engine(H, c, c, 1, 1, torch.bfloat16, batch, res=True)
+            x = torch.randn(batch, c, H, H, generator=g).cuda()
+            V = torch.randn(batch, c * H * H, generator=g).cuda()
+            U = torch.randn(batch, c * H * H, generator=g).cuda()
+            outs = {}
+            for tile in (515, 530):
+                L.check(lib.dpb_debug_set(b"gemm_splitk", 1)); L.check(lib.dpb_debug_set(b"gemm_tile", tile))
+                e.primal(x, 1.0, None, "o")
+                outs[tile] = (e.read("o").clone(), e.jvp("o", V).clone(), e.vjp("o", U).clone())
+            for a, b, name in zip(outs[515], outs[530], ("primal", "jvp", "vjp")):
+                assert torch.isfinite(b).all() and torch.equal(a, b), f"residual case {(H, c, batch)} {name}: max |d| = {(a - b).abs().max().item():.3e}"
+            del e
         for (H, cin, cout, ks, batch) in [(16, 256, 256, 1, 1), (16, 512, 512, 1, 2), (64, 2560, 2560, 1, 1), (32, 640, 640, 3, 5)]:
             e, _ = engine(H, cin, cout, ks, 1, torch.bfloat16, batch)
             x = torch.randn(batch, cin, H, H, generator=g).cuda()

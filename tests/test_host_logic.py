@@ -213,7 +213,9 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
     # the launch that overflowed: now the 256x256 tile, unsplit; and the same product forced onto the 128x128 ring keeps within the scratch
     assert plan(L.DPB_BF16, 10240, 1280, 5120) == (2, 530, 1)
     assert plan(L.DPB_BF16, 20480, 320, 2880, 64, 320)[0] == 3            # N = 320 (37.5 % padding on 256-column tiles): the halo-tile kernel keeps the 64x64-level convolutions
-    assert plan(L.DPB_BF16, 40960, 640, 5760, 32, 640)[:2] == (2, 530)     # many samples advanced together: the 8-phase tile takes the 3x3 convolutions
+    assert plan(L.DPB_BF16, 20480, 640, 5760, 32, 640)[:2] == (2, 530)     # 20 tangents: the 8-phase tile takes the 32x32-level 3x3 convolutions
+    assert plan(L.DPB_BF16, 81920, 640, 5760, 32, 640)[0] == 3             # 80 tangents, N = 640 (17 % padding): the halo-tile kernel is ahead again
+    assert plan(L.DPB_BF16, 20480, 1280, 11520, 16, 1280)[:2] == (2, 530)  # N = 1280: no padding, the 8-phase tile
     # fused GEGLU epilogues: FF-in tangent (N = 2F interleaved) and FF-out adjoint (N = F) of every level go to ring kernels, unsplit
     for M, F, Cc in ((20480, 1280, 320), (5120, 2560, 640), (1280, 5120, 1280), (40960, 2560, 640), (2560, 5120, 1280)):
         for epi, N, K in ((1, 2 * F, Cc), (2, F, Cc)):

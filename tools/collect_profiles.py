@@ -18,6 +18,7 @@ import sys
 SRC_TAG = sys.argv[1]
 DST_TAG = sys.argv[2] if len(sys.argv) > 2 else SRC_TAG
 SRC, DST = "gpurun_out", "profiles"
+TRACE_ITERS = 48.0      # tools/gpu_session.sh traces `bench.py --steps 36 --warmup 12 --profile-run`: 48 power iterations (+ 4 primal passes, ~2 % of the product time)
 PMC_ITERS = 12.0        # tools/pmc_mfma.sh profiles `bench.py --steps 12 --warmup 0 --profile-run`: one sample, 12 power iterations
 
 
@@ -30,6 +31,36 @@ def label(name):
         keep = 3 if m.group(1) != "gemm_kernel" else 4
         return f"{m.group(1)}<{','.join(m.group(2).split(',')[:keep])}>"
     return name
+
+
+def kind_of(name):
+    """kernel-trace name -> the GEMM kernel kind of dpb_engine_profile_read (include/dpb.h), or None"""
+    name = re.sub(r"^void\s+", "", name).replace("dpb::", "").replace(" ", "")
+    m = re.match(r"(gemm_kernel|gemm_dma_kernel|gemm_ring64_kernel|conv_halo_kernel|gemm_p8_kernel)<(.*)>", name)
+    if not m:
+        return None
+    fam, par = m.group(1), m.group(2).split(",")
+    if fam == "gemm_kernel":
+        return 1 if par[1] == "128" else 0
+    if fam == "gemm_dma_kernel":
+        return 3 if par[0] == "64" else 2
+    if fam == "gemm_ring64_kernel":
+        return 6 if par[0] == "256" and par[1] == "256" else 4
+    return 5 if fam == "conv_halo_kernel" else 11
+
+
+def trace_by_kind(path):
+    """per-iteration kernel time and launches of every GEMM kernel kind from a rocprofv3 --kernel-trace --stats CSV"""
+    import csv
+    out = {}
+    for r in csv.DictReader(open(path)):
+        k = kind_of(r["Name"])
+        if k is None:
+            continue
+        e = out.setdefault(str(k), {"ms_per_iter": 0.0, "launches_per_iter": 0.0})
+        e["ms_per_iter"] += float(r["TotalDurationNs"]) / 1e6 / TRACE_ITERS
+        e["launches_per_iter"] += float(r["Calls"]) / TRACE_ITERS
+    return out
 
 
 def main():
@@ -67,6 +98,11 @@ def main():
                    "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 12 --warmup 0 "
                               "--no-cpu-baseline --no-roofline (SD-1.5 mid, k=5, bf16, 1 sample); tools/pmc_mfma.sh",
                    "_units": "KB per launch as reported by rocprofv3; gfx950: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM section)",
+                   "_trace": ({"source": f"profiles/{DST_TAG}_sd15_mid_k5_bf16_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --steps 36 --warmup 12 --profile-run, "
+                                         "same session and library as the counter passes): kernel time per power iteration by GEMM kernel kind "
+                                         "(dpb_engine_profile_read's kinds); includes the 4 primal passes of the run (~2 % of the product time)",
+                               "iterations": TRACE_ITERS, "by_kind": trace_by_kind(os.path.join(SRC, f"{SRC_TAG}_stats/sd15_kernel_stats.csv"))}
+                              if os.path.exists(os.path.join(SRC, f"{SRC_TAG}_stats/sd15_kernel_stats.csv")) else None),
                    "_src_hash": src_hash,      # source hash of the libdpb.so the counters were collected on (bench.py quotes them only for that build)
                    "kernels": kernels}, open(os.path.join(DST, f"{DST_TAG}_pmc_traffic_sd15_mid_k5_bf16.json"), "w"), indent=1)
     print("profiles/:", sorted(f for f in os.listdir(DST) if f.startswith(DST_TAG)))
