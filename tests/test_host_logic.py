@@ -37,6 +37,14 @@ def test_cli_preset_rules(tmp_path):
     a = m.preset(m.parse_args(["--note", "t", "--model_name", "stabilityai/stable-diffusion-2-1-base", "--dataset_name", "Examples",
                                "--result_folder", str(tmp_path), "--edit_t", "0.7", "--some_dead_flag", "1"]))
     assert a.is_stable_diffusion and (a.c_in, a.image_size, a.memory_bound) == (4, 64, 5)
+    assert a.trajectory_batch == 20                                   # default: the (pc, +-) trajectories advance together
+    # an EXPLICIT --memory_bound also caps the trajectory batching (the reference then resets memory_bound itself to its per-model constant)
+    c = m.preset(m.parse_args(["--note", "t", "--model_name", "stabilityai/stable-diffusion-2-1-base", "--dataset_name", "Examples",
+                               "--result_folder", str(tmp_path), "--memory_bound", "2"]))
+    assert c.memory_bound == 5 and c.trajectory_batch == 2
+    d = m.preset(m.parse_args(["--note", "t", "--model_name", "stabilityai/stable-diffusion-2-1-base", "--dataset_name", "Examples",
+                               "--result_folder", str(tmp_path), "--memory_bound=3", "--trajectory_batch", "8"]))
+    assert d.trajectory_batch == 3
     b = m.preset(m.parse_args(["--note", "u", "--model_name", "CelebA_HQ_HF", "--dataset_name", "CelebA_HQ", "--result_folder", str(tmp_path),
                                "--performance_boosting_t", "0.2", "--use_x_space_guidance", "True", "--h_t", "0.6"]))
     assert not b.is_stable_diffusion and b.memory_bound == 50 and b.x_space_guidance_scale == 4
