@@ -69,11 +69,17 @@ def parse_args(argv=None):
         p.add_argument("--" + name, type=typ, default=default, required=False)
     p.add_argument("--note", type=str, required=True)
     args, extra = p.parse_known_args(argv)
-    # an explicitly given --memory_bound also bounds the trajectory batching below (the reference then resets memory_bound itself to its per-model
-    # constant, define_argparser.py:211-221 -- kept in preset() -- but a user who passed a bound to fit memory must not get 20 latents per call)
+    # An explicitly given --memory_bound also bounds the trajectory batching below.  (The reference has no such flag: define_argparser.py:211-221 sets
+    # memory_bound to a per-model constant -- kept in preset() -- so the flag arrives among the unknown ones; a user who passes it to fit memory must
+    # not get 20 latents per call.)
     import sys as _sys
-    given = [a for a in (argv if argv is not None else _sys.argv[1:]) if a == "--memory_bound" or a.startswith("--memory_bound=")]
-    args.memory_bound_given = args.memory_bound if given else 0
+    av = list(argv if argv is not None else _sys.argv[1:])
+    args.memory_bound_given = 0
+    for i, tok in enumerate(av):
+        val = tok.split("=", 1)[1] if tok.startswith("--memory_bound=") else (av[i + 1] if tok == "--memory_bound" and i + 1 < len(av) else None)
+        if val is not None:
+            args.memory_bound_given = max(1, int(val))
+            extra = [e for e in extra if e not in (tok, val)]
     if extra:
         print(f"note: ignoring flags of experiments outside the pullback path: {extra}")
     return args
