@@ -536,26 +536,40 @@ def main():
         traffic, tnote = pmc_traffic(dom, headline_cfg)
         trace, trnote = trace_time_by_kind(headline_cfg)
         tr = trace.get(str(KIND_OF[dom])) if trace else None
-        if tr and tr["ms_per_iter"] > 0:                                 # time from the hash-matched kernel trace, algorithmic flops from this run's launches
-            ach_tr = fl_d / (tr["ms_per_iter"] * 1e-3) / 1e12
-            frac_main, frac_src = ach_tr / PEAK[dname], "rocprofv3 kernel trace (hash-matched profiles/): " + trnote
+        # `achieved` / `frac` are THIS run's measurement: algorithmic flops of the dominant kind's launches over their HIP-event bracket times minus the empty-bracket
+        # time calibrated in this run (dpb_engine_profile_overhead).  The committed rocprofv3 kernel trace is a cross-check under its own keys (`*_trace`), and only when
+        # it was taken on this build, with the same dispatch (launch count of the dominant kind agrees, no dispatch switch set in the environment).
+        switches = sorted(v for v in os.environ if v.startswith("DPB_") and v not in ("DPB_PROFILE_CSV", "DPB_LIB"))
+        ach_tr = frac_tr = None
+        if not tr or tr["ms_per_iter"] <= 0:
+            tr_why = trnote
+        elif switches:
+            tr_why = "not compared: dispatch switches set in the environment (%s)" % ", ".join(switches)
+        elif abs(tr["launches_per_iter"] - n_d) > 0.05 * max(n_d, 1):      # (the trace averages over iterations AND the run's primal passes: ~2 % more launches)
+            tr_why = "not compared: the committed trace has %.1f launches of this kind per iteration, this run %d" % (tr["launches_per_iter"], n_d)
         else:
-            ach_tr, frac_main, frac_src = None, ach / PEAK[dname], "raw HIP events of this run (" + trnote + ")"
+            ach_tr = fl_d / (tr["ms_per_iter"] * 1e-3) / 1e12
+            frac_tr, tr_why = ach_tr / PEAK[dname], trnote
+        frac_main = ach_corr / PEAK[dname]
+        frac_src = ("HIP events of this run around every launch of the kind on the engine stream, minus the empty-bracket time calibrated in this run "
+                    "(raw brackets: frac_events_raw; committed rocprofv3 kernel trace of the same build: frac_trace)")
         step_bytes, snote = pmc_step_bytes(headline_cfg)
         ms_step = 1e3 * dt / (steps if not strong else max(1, len(mine) * ITERS_PER_SAMPLE))
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach_tr if ach_tr is not None else ach, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": frac_main,
+        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach_corr, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": frac_main,
                            "frac_source": frac_src, "achieved_events_raw": ach, "frac_events_raw": ach / PEAK[dname],
+                           "achieved_trace": ach_tr, "frac_trace": frac_tr, "trace_note": tr_why,
+                           "trace_agrees_with_events": (abs(ach_tr - ach_corr) <= 0.1 * ach_tr) if ach_tr else None,
                            "trace_ms_per_iteration": tr["ms_per_iter"] if tr else None, "trace_launches_per_iteration": tr["launches_per_iter"] if tr else None,
                            "traffic": traffic, "traffic_note": tnote,
                            "launches_per_pass": n_d, "avg_launch_us": 1e3 * ms_d / max(n_d, 1), "flops_per_pass": fl_d,
                            "event_bracket_overhead_us": 1e3 * ovh_ms,
                            "achieved_bracket_corrected": ach_corr, "frac_bracket_corrected": ach_corr / PEAK[dname],
                            "avg_launch_us_bracket_corrected": 1e3 * ms_c / max(n_d, 1),
-                           "timing_note": "`achieved` / `frac`: algorithmic flops of the dominant kernel kind's launches (this run) over its kernel time per iteration in the "
-                                          "committed rocprofv3 kernel trace when that trace was taken on this build (frac_source says which); otherwise, and always in "
-                                          "`*_events_raw`, HIP events around every launch on the engine stream (flops / sum of raw bracket "
-                                          "times); `*_bracket_corrected` subtract a calibrated empty-bracket time per launch (event_bracket_overhead_us) and sit closer "
-                                          "to the rocprofv3 kernel trace under profiles/, which lies between the two",
+                           "timing_note": "`achieved` / `frac` (= `*_bracket_corrected`): algorithmic flops of the dominant kernel kind's launches over their HIP-event "
+                                          "bracket times on the engine stream minus a calibrated empty-bracket time per launch (event_bracket_overhead_us), all measured in "
+                                          "this run; `*_events_raw`: the same without the correction (an event pair costs about as much as a small kernel); `*_trace`: the "
+                                          "same flops over the kind's kernel time in the committed rocprofv3 kernel trace of this build under profiles/ (cross-check only, "
+                                          "null when build or dispatch differ: trace_note)",
                            "all_gemm_kernels": {n: {"launches": v[0], "avg_launch_us": 1e3 * raw_ms[n] / max(v[0], 1),
                                                     "achieved": v[2] / (raw_ms[n] * 1e-3) / 1e12 if v[0] > 0 else 0.0,
                                                     "achieved_bracket_corrected": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for n, v in kinds.items()},

@@ -23,6 +23,9 @@
 
 namespace dpb {
 
+#ifndef DPB_ATT_ABL
+#define DPB_ATT_ABL 0     // measurement-only builds (make ablate_attn, tools/gpu_attn_ablate.sh; WRONG results): bit 0 drops a quarter of the head-dim-side MFMAs of the
+#endif                    // d = 40 kernels (what 16x16x32 tiles would save), bit 1 one of the six dS MFMAs of the tangent kernel (a stacked [K | dK] product), bit 2 the exp
 #define DPB_ATT_PAD 8     // row padding (bf16 elements) of the LDS [row][d] tiles (16 / 24 measured in round 3: 9.02 / 9.28 vs 8.99 ms per iteration)
 
 constexpr int att_waves(int d) { return d > 80 ? 4 : 8; }   // waves per block: 8 x 32 = 256 outer rows share every streamed tile
@@ -352,7 +355,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
       for (int stp = 0; stp < F::NS; ++stp) {
         s = MFMA(kf[stp], qf[stp], s);
         ds = MFMA(kf[stp], dqf[stp], ds);
-        ds = MFMA(dkf[stp], qf[stp], ds);
+        if (!((DPB_ATT_ABL & 2) && D == 40 && stp == F::NS - 1)) ds = MFMA(dkf[stp], qf[stp], ds);
       }
       if constexpr (PIPE) {
         __builtin_amdgcn_sched_barrier(0);
@@ -362,7 +365,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
       float p[16], x[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(c2 * s[r] - m2);
+        p[r] = (DPB_ATT_ABL & 4) ? c2 * s[r] - m2 : __builtin_amdgcn_exp2f(c2 * s[r] - m2);
         x[r] = p[r] * (a.scale * ds[r]);
         if constexpr (!SUMROW) delta += x[r];
       }
@@ -377,6 +380,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
             vf[ks][d] = lds_tr_frag(sV, F::LDR, kb * 32 + ks * 16, d * 32, lane);
             dvf[ks][d] = lds_tr_frag(sdV, F::LDR, kb * 32 + ks * 16, d * 32, lane);
           }
+          if ((DPB_ATT_ABL & 1) && D == 40 && ks == 1 && d == 1) continue;
           acc[d] = MFMA(vf[ks][d], xb[ks], acc[d]);
           acc[d] = MFMA(dvf[ks][d], pb[ks], acc[d]);
         }
@@ -604,7 +608,10 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int d = 0; d < F::ND; ++d) acc[t][d] = MFMA(ktf[ks][d], gsb[ks], acc[t][d]);
+            for (int d = 0; d < F::ND; ++d) {
+              if ((DPB_ATT_ABL & 1) && D == 40 && ks == 1 && d == 1) continue;
+              acc[t][d] = MFMA(ktf[ks][d], gsb[ks], acc[t][d]);
+            }
         }
       }
     }
@@ -949,6 +956,7 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int d = 0; d < S::ND; ++d) {
+            if ((DPB_ATT_ABL & 1) && D == 40 && ks == 1 && d == 1) continue;
             accV[d] = MFMA(lds_tr_frag(sgO, S::LDR, qb * 32 + ks * 16, d * 32, lane), *reinterpret_cast<bf16x8*>(&pw[ks]), accV[d]);
             accK[d] = MFMA(lds_tr_frag(sQ, S::LDR, qb * 32 + ks * 16, d * 32, lane), gsb[ks], accK[d]);
           }

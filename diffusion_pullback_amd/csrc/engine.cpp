@@ -174,18 +174,14 @@ int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false) {
   e->gbytes += ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * a.Z1 * a.Z2 * e->es;
   int nl = 1;                                   // kernels enqueued: the product itself (+ splitk_reduce_kernel for split-K launches)
   if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl, pend); e->n_launch += nl; e->pend.on = pend && pend->splitk > 1; return r; }
-  dpb_engine::Prof p;
-  p.flops = 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2;
-  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); p.big = gemm_uses_halo(e->dtype, az) ? 5 : dm == 530 ? 11 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile, 11: 8-phase 256x256 tile (gemm_p8.hip)
-  p.M = a.M; p.N = a.N; p.K = a.K; p.Z = a.Z1 * a.Z2; p.gather = a.gather;
-  DPB_CHECK(hipEventCreate(&p.a));
-  DPB_CHECK(hipEventCreate(&p.b));
-  DPB_CHECK(hipEventRecord(p.a, e->stream));
+  int kind;
+  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); kind = gemm_uses_halo(e->dtype, az) ? 5 : dm == 530 ? 11 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile, 11: 8-phase 256x256 tile (gemm_p8.hip)
+  // the same bracket helpers as the attention launches (an event that cannot be created or recorded costs the bracket, never leaks its partner)
+  const int pi = prof_open(e, 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2, kind, a.M, a.N, a.K, a.Z1 * a.Z2, a.gather);
   int r = launch_gemm(e->dtype, a, e->stream, &nl, pend);
   e->n_launch += nl;
   e->pend.on = pend && pend->splitk > 1;
-  DPB_CHECK(hipEventRecord(p.b, e->stream));
-  e->prof.push_back(p);
+  prof_close(e, pi);
   return r;
 }
 
@@ -1296,6 +1292,7 @@ int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double*
   *count = 0; *total_ms = 0; *flops = 0;
   const bool raw = big_tile >= 1000;                 // kind + 1000: the RAW bracket times (no empty-bracket correction, nothing clamped)
   if (raw) big_tile -= 1000;
+  if (big_tile < 0 || big_tile > 11) return fail("dpb_engine_profile_read: kind must be 0..11 or 1000..1011");
   for (auto& p : e->prof) {
     if (p.big != big_tile) continue;
     float ms = 0;

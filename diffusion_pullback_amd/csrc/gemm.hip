@@ -495,7 +495,7 @@ static const ShapeOverride* find_override(const GemmArgs& a) {
 // halo-tile kernel: N = 1280 +16-19 %, N = 640 +10 % at 20 tangents and equal at 80).
 static int p8_wants(int dtype, const GemmArgs& a) {
   static const int p8_env = getenv("DPB_P8") ? atoi(getenv("DPB_P8")) : 1;      // tuning switch (0: rings / halo kernel as in round 4)
-  if (!p8_env || !g_p8 || dtype == DT_F32 || a.A2 || !a.zeros || a.Z1 * a.Z2 != 1 || a.K % 8) return 0;
+  if (!p8_env || !g_p8 || dtype == DT_F32 || a.A2 || !a.zeros || a.Z1 * a.Z2 != 1 || a.K % 8 || !gemm_p8_fits32(a)) return 0;
   if (a.gather != GATHER_NONE && (a.Cin % 64 || a.epi != EPI_PLAIN)) return 0;
   if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ || (a.epi != EPI_PLAIN && a.N % 256)) return 0;
   const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), rounds = (t256 + 255) / 256;

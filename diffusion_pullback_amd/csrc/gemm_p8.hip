@@ -77,6 +77,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   constexpr int AREA = 65536, HALF = 32768, PAR = 16384;       // LDS bytes: operand area, half, K-tile parity
   constexpr int WN = 64, SLD = WN + 4;
   static_assert(8 * 32 * SLD * 4 <= 2 * AREA, "epilogue staging fits the ring");
+  // The counted waits of the K loop.  vmcnt counts this wave's VMEM instructions, oldest retired first: every stage_a / stage_b call issues exactly
+  // DMA_PER_STAGE LDS-DMA instructions per lane (16 KiB half tile = 8 waves x DMA_PER_STAGE x 1 KiB), nothing else is in the vector-memory queue inside
+  // the loop, and the waits below are "all but the youngest n stages".  Change the pieces per stage (tile size, 8-byte pieces, ...) and the waits follow.
+  constexpr int DMA_PER_STAGE = 2;
+  constexpr int VM_PH3 = 5 * DMA_PER_STAGE;   // phase 3: B0(s+1) landed; A0 B1 A1 of s+1 and B0 A0 of s+2 (five stages) stay in flight
+  constexpr int VM_PH4 = 3 * DMA_PER_STAGE;   // phase 4 / prologue: K tile s+1 landed; B0 A0 B1 of s+2 (three stages) stay in flight
+  static_assert(PAR == 8 * DMA_PER_STAGE * 1024, "a half tile of one parity = 8 waves x DMA_PER_STAGE pieces of 1 KiB");
+  static_assert(VM_PH3 == 10 && VM_PH4 == 6 && VM_PH3 < 64, "the schedule in the header comment (vmcnt(10) / vmcnt(6)) assumes two pieces per stage");
   __shared__ __attribute__((aligned(1024))) char smem[2 * AREA];
   const unsigned lds0 = (unsigned)(uintptr_t)(p8_lds_t*)smem;
 
@@ -115,8 +123,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   // the swizzle key (row >> 1) & 7 = ((wave & 1) << 2) | ((lane >> 4) & 3) is the same for every slot of the lane, so is its K offset kl.
   const int kl = ((lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3))) * CH;
   const int Cin = p.Cin, Wd = p.W, Hd = p.H, lda = p.lda, strd = p.stride, pad = p.pad, KS = p.KS;
-  const bf16* a_base[4];             // slot sa = h*2 + j
-  const bf16* a_cur[4];
+  // Row addresses are 32-bit ELEMENT offsets from the wave-uniform A / B (P8_NOROW = no such row: the DMA reads the zero page); the launcher routes
+  // operands of 2^32 elements or more to the ring kernels.  (As 64-bit pointers the gather variants spilled two VGPRs, reloaded -- behind a full
+  // vmcnt(0) drain of the DMA queue -- at every filter-tap change inside the K loop: tests/test_host_logic.py reads the ISA for scratch use.)
+  constexpr unsigned P8_NOROW = 0xffffffffu;
+  unsigned a_base[4];                // slot sa = h*2 + j
+  unsigned a_cur[4];
   int a_oyx[4];
   int kca[2], tapa[2], cca[2];       // per half: the two slots of a half advance together
   auto retap = [&](int sa, int tap) {
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
       if (KS == 3) { ky = (tap * 11) >> 5; kx = tap - ky * 3; }
       const int oy = a_oyx[sa] >> 16, ox = a_oyx[sa] & 0xffff;
       int iy, ix;
-      bool ok = a_base[sa] != nullptr;
+      bool ok = a_base[sa] != P8_NOROW;
       if constexpr (GATHER == GATHER_CONV) {
         iy = oy * strd + ky - pad;
         ix = ox * strd + kx - pad;
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         ok = ok && uy >= 0 && ux >= 0 && uy < 2 * Hd && ux < 2 * Wd;
         iy = uy >> 1; ix = ux >> 1;
       }
-      a_cur[sa] = ok ? a_base[sa] + ((long)iy * Wd + ix) * lda : nullptr;
+      a_cur[sa] = ok ? a_base[sa] + (unsigned)(iy * Wd + ix) * (unsigned)lda : P8_NOROW;
     }
   };
 #pragma unroll
@@ -160,16 +172,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
       const int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
       a_oyx[sa] = 0;
       if constexpr (GATHER == GATHER_NONE) {
-        a_base[sa] = m < p.M ? A + (long)m * lda : nullptr;
+        a_base[sa] = m < p.M ? (unsigned)m * (unsigned)lda : P8_NOROW;
       } else {
         const int hw = p.Ho * p.Wo, smp = m / hw, rem = m - smp * hw, oy = rem / p.Wo;
         a_oyx[sa] = (oy << 16) | (rem - oy * p.Wo);
-        a_base[sa] = m < p.M ? A + (long)smp * Hd * Wd * lda : nullptr;
+        a_base[sa] = m < p.M ? (unsigned)(smp * Hd * Wd) * (unsigned)lda : P8_NOROW;
       }
       retap(sa, tapa[h]);
     }
   }
-  const bf16* b_base[4];
+  unsigned b_base[4];
   int kcb[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j) {
       const int r = (j * 8 + wave) * 8 + (lane >> 3);
       const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-      b_base[h * 2 + j] = n < p.N ? B + (long)n * p.ldb : nullptr;
+      b_base[h * 2 + j] = n < p.N ? (unsigned)n * (unsigned)p.ldb : P8_NOROW;
     }
   }
   // FAST: byte offsets of the lane's rows from the block's first row / column (clamped into the matrix), K position as a uniform byte offset
@@ -209,12 +221,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     if constexpr (FAST) {
       const char* sb = Ab + min(kua[h], kumax);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)aoff[h * 2 + j]), (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
+      for (int j = 0; j < DMA_PER_STAGE; ++j) __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)aoff[h * 2 + j]), (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
       kua[h] += BK * 2;
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16* src = (a_cur[h * 2 + j] && kca[h] < kend) ? a_cur[h * 2 + j] + cca[h] : zero;
+      for (int j = 0; j < DMA_PER_STAGE; ++j) {
+        const bf16* src = (a_cur[h * 2 + j] != P8_NOROW && kca[h] < kend) ? A + (unsigned long)(a_cur[h * 2 + j] + (unsigned)cca[h]) : zero;
         __builtin_amdgcn_global_load_lds((p8_gbl_t*)src, (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
       }
       kca[h] += BK;
@@ -235,12 +247,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     if constexpr (FAST) {
       const char* sb = Bb + min(kub[h], kumax);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)boff[h * 2 + j]), (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
+      for (int j = 0; j < DMA_PER_STAGE; ++j) __builtin_amdgcn_global_load_lds((p8_gbl_t*)(sb + (unsigned long)boff[h * 2 + j]), (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
       kub[h] += BK * 2;
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16* src = (b_base[h * 2 + j] && kcb[h] < kend) ? b_base[h * 2 + j] + kcb[h] : zero;
+      for (int j = 0; j < DMA_PER_STAGE; ++j) {
+        const bf16* src = (b_base[h * 2 + j] != P8_NOROW && kcb[h] < kend) ? B + (unsigned long)(b_base[h * 2 + j] + (unsigned)kcb[h]) : zero;
         __builtin_amdgcn_global_load_lds((p8_gbl_t*)src, (p8_lds_t*)(dst + j * 8192), 16, 0, 0);
       }
       kcb[h] += BK;
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     // phase 3: a1 x b0
     read_a(I1{}, D{});
     stage_a(I0{}, D{});
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // B0 of K tile s+1 (issued five phases ago) has landed: read it in phase 4
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PH3) : "memory");    // B0 of K tile s+1 (issued five phases ago) has landed: read it in phase 4
     bar();
     p8_wait8(fa);
     mma(I1{}, I0{}, fb0);
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     // phase 4: a1 x b1, and b0 of the next K tile
     read_b(I0{}, DX{}, fb0);
     stage_b(I1{}, D{});
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // the rest of K tile s+1 has landed (this wave's share); B0 / A0 / B1 of s+2 stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PH4) : "memory");     // the rest of K tile s+1 has landed (this wave's share); B0 / A0 / B1 of s+2 stay in flight
     bar();
     mma(I1{}, I1{}, fb1);
     p8_wait4(fb0);                                        // retired before this phase's second barrier: B0[d^1] may be restaged in phase 2 of the next tile
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
   if (nk > 0) {
     stage_b(I0{}, I0{}); stage_a(I0{}, I0{}); stage_b(I1{}, I0{}); stage_a(I1{}, I0{});      // K tile 0
     stage_b(I0{}, I1{}); stage_a(I0{}, I1{}); stage_b(I1{}, I1{});                            // K tile 1 without its A1 half (phase 1 of tile 0)
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM_PH4) : "memory");
     bar();
     read_b(I0{}, I0{}, fb0);
     p8_wait4(fb0);                                   // retired before the first barrier of the loop: B0[0] is restaged in phase 2 of K tile 0
@@ -474,9 +486,17 @@ static void launch_p8_f(const GemmArgs& a, dim3 grid, hipStream_t st) {
 #undef DPB_P8
 }
 
+// the kernel addresses operand rows by 32-bit element offsets from A / B (per batch entry)
+bool gemm_p8_fits32(const GemmArgs& a) {
+  double ea = (double)a.M * a.lda;
+  if (a.gather != GATHER_NONE && a.Ho > 0 && a.Wo > 0) ea = ((double)((a.M + a.Ho * a.Wo - 1) / (a.Ho * a.Wo)) + 1.0) * a.H * a.W * a.lda;
+  return ea + a.K < 4294967295.0 && (double)a.N * a.ldb + a.K < 4294967295.0;
+}
+
 // tile code 530: 256 x 256 x 64, 8 waves, 4 phases per K tile
 int launch_gemm_p8(const GemmArgs& a, int tile, hipStream_t st) {
   if (tile != 530) { set_error("gemm: unknown 8-phase tile code %d", tile); return -1; }
+  if (!gemm_p8_fits32(a)) { set_error("gemm: the 8-phase tile addresses operands by 32-bit element offsets (M = %d, lda = %d, N = %d, ldb = %d)", a.M, a.lda, a.N, a.ldb); return -1; }
   if (a.epi == EPI_LN_TAN || a.epi == EPI_LN_ADJ || (a.epi != EPI_PLAIN && a.gather != GATHER_NONE)) { set_error("gemm: the 8-phase tile has the plain and GEGLU epilogues only"); return -1; }
   if (a.gather != GATHER_NONE && a.Cin % 64) { set_error("gemm: the 8-phase tile gathers whole 64-channel K tiles (Cin = %d)", a.Cin); return -1; }
   const int sk = a.splitk > 1 ? a.splitk : 1;

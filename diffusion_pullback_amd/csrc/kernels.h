@@ -59,6 +59,7 @@ void gemm_debug_set(int tile, int splitk, int kch);
 int gemm_kch(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, int tile, hipStream_t st);   // bf16, single operand pair, no split-K (gemm_dma.hip); tile 128 | 64 | 66 (64 with a 6-stage ring)
 int launch_gemm_ring64(const GemmArgs& a, int tile, hipStream_t st);   // BK = 64 ring (gemm_ring64.hip); tile 512 | 513 | 514 | 515
+bool gemm_p8_fits32(const GemmArgs& a);                                // its 32-bit element offsets reach every operand row
 int launch_gemm_p8(const GemmArgs& a, int tile, hipStream_t st);      // 8-phase ping-pong loop (gemm_p8.hip); tile 530 = 256x256x64, 8 waves
 int conv_halo_supported(const GemmArgs& a);                        // 3x3 stride-1 convolution in halo-tile form (gemm_halo.hip)
 int launch_conv_halo(const GemmArgs& a, hipStream_t st);

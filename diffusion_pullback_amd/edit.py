@@ -108,6 +108,7 @@ class EditStableDiffusion(_EditBase):
         # in one U-Net call per step, their decode trajectories in one batch -- instead of one after another as edit.py:276-307 does.  Samples are
         # independent in every kernel, so files, names and tensors are the same; the GPU sees 4x fewer, 4x fatter launches.  0 / 1: the reference's order.
         self.trajectory_batch = int(getattr(args, "trajectory_batch", 0) or 0)
+        self.memory_bound_given = getattr(args, "memory_bound_given", None)      # explicit --memory_bound: bounds every U-Net call (floor: the pair of x-space guidance)
         self.unet = unet
         self.vae = vae
         self.dtype = getattr(args, "dtype", torch.float32)
@@ -312,6 +313,8 @@ class EditStableDiffusion(_EditBase):
         chain = [z]
         cap = getattr(getattr(self.unet, "engine", None), "max_batch", None) or 2 * n
         per = max(1, min(n, cap // 2))                                                          # chains per U-Net call
+        if self.memory_bound_given:
+            per = max(1, min(per, self.memory_bound_given // 2))
         for _ in range(self.x_space_guidance_num_step):
             nxt = []
             for zc, vc in zip(z.split(per), vk.split(per)):

@@ -59,6 +59,7 @@ _FLAGS = [  # (name, type, default) -- define_argparser.py:20-110, live path onl
     # U-Net batch of the edit trajectories: the 2 * vis_num_pc independent (pc, +-) edits of edit.py:276-307 run together (x-space guidance as one batch-2n call per
     # step, the n * (vis_num + 1) decode trajectories as one batch).  Same files, tensors equal up to 16-bit rounding (tile / split-K choices depend on the batch);
     # 0 / 1 = one experiment after another, memory_bound latents per call (the setting for bitwise-reproducible runs); an explicit --memory_bound caps it
+    # (and replaces the per-model memory_bound constant: it is then the bound of every U-Net call, the 2 of an x-space-guidance pair being the floor)
     ("trajectory_batch", int, 20),
 ]
 
@@ -68,18 +69,13 @@ def parse_args(argv=None):
     for name, typ, default in _FLAGS:
         p.add_argument("--" + name, type=typ, default=default, required=False)
     p.add_argument("--note", type=str, required=True)
+    # --memory_bound is NOT a flag of the reference (define_argparser.py:211-221 sets memory_bound to a per-model constant, kept in preset()); here an explicit
+    # value is the user's bound on the U-Net batch -- decode chunks, trajectory batching, the guidance chains per call and the engine's max_batch all respect it
+    p.add_argument("--memory_bound", type=int, default=None)
     args, extra = p.parse_known_args(argv)
-    # An explicitly given --memory_bound also bounds the trajectory batching below.  (The reference has no such flag: define_argparser.py:211-221 sets
-    # memory_bound to a per-model constant -- kept in preset() -- so the flag arrives among the unknown ones; a user who passes it to fit memory must
-    # not get 20 latents per call.)
-    import sys as _sys
-    av = list(argv if argv is not None else _sys.argv[1:])
-    args.memory_bound_given = 0
-    for i, tok in enumerate(av):
-        val = tok.split("=", 1)[1] if tok.startswith("--memory_bound=") else (av[i + 1] if tok == "--memory_bound" and i + 1 < len(av) else None)
-        if val is not None:
-            args.memory_bound_given = max(1, int(val))
-            extra = [e for e in extra if e not in (tok, val)]
+    if args.memory_bound is not None and args.memory_bound < 1:
+        p.error("--memory_bound must be a positive integer")
+    args.memory_bound_given = args.memory_bound
     if extra:
         print(f"note: ignoring flags of experiments outside the pullback path: {extra}")
     return args
@@ -114,14 +110,15 @@ def preset(args):
     args.dtype = torch.float32                      # boundary dtype of latents
     if args.use_x_space_guidance:
         args.x_space_guidance_scale = X_SPACE_GUIDANCE_SCALE_DICT["stable-diffusion" if args.is_stable_diffusion else "uncond"][args.h_t]
-    if getattr(args, "memory_bound_given", 0) > 0:
-        args.trajectory_batch = min(args.trajectory_batch, args.memory_bound_given)
+    given = getattr(args, "memory_bound_given", None)
+    if given:
+        args.trajectory_batch = min(args.trajectory_batch, given)
     if args.is_stable_diffusion:
-        args.c_in, args.image_size, args.memory_bound = 4, 64, 5
+        args.c_in, args.image_size, args.memory_bound = 4, 64, given or 5
         assert args.use_yh_custom_scheduler
         assert args.performance_boosting_t <= 0
     else:
-        args.c_in, args.image_size, args.memory_bound, args.noise_schedule = 3, 256, 50, "linear"
+        args.c_in, args.image_size, args.memory_bound, args.noise_schedule = 3, 256, given or 50, "linear"
         assert args.use_yh_custom_scheduler
         assert args.for_steps == 100
         assert args.performance_boosting_t == 0.2

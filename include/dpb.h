@@ -161,7 +161,8 @@ int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops,
  * 8 fused self-attention tangent, 9 fused self-attention adjoint (its query-major and key-major launches in ONE bracket; the CSV's `gather`
  * column holds the route: bit 0 multi-cotangent query-major kernel, bit 1 shared-probability key-major kernel), 10 one-launch cross-attention
  * tangent (gather 0) / adjoint (gather 1): 2 L x 77 x d products.  kind + 1000 returns the RAW bracket times of that kind (without the empty-bracket
- * correction of dpb_engine_profile_overhead, which clamps a bracket shorter than the correction to 0).  _dump writes one CSV line per recorded bracket. */
+ * correction of dpb_engine_profile_overhead, which clamps a bracket shorter than the correction to 0); any other kind (neither 0..11 nor 1000..1011) fails.
+ * _dump writes one CSV line per recorded bracket. */
 int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
 int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);

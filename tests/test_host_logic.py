@@ -38,13 +38,28 @@ def test_cli_preset_rules(tmp_path):
                                "--result_folder", str(tmp_path), "--edit_t", "0.7", "--some_dead_flag", "1"]))
     assert a.is_stable_diffusion and (a.c_in, a.image_size, a.memory_bound) == (4, 64, 5)
     assert a.trajectory_batch == 20                                   # default: the (pc, +-) trajectories advance together
-    # an EXPLICIT --memory_bound also caps the trajectory batching (the reference then resets memory_bound itself to its per-model constant)
+    # an EXPLICIT --memory_bound (not a flag of the reference, which only knows the per-model constant) is the bound of every U-Net call: it replaces the
+    # constant, caps the trajectory batching, the guidance chains per call and the engine's max_batch (floor: the pair of x-space guidance)
     c = m.preset(m.parse_args(["--note", "t", "--model_name", "stabilityai/stable-diffusion-2-1-base", "--dataset_name", "Examples",
-                               "--result_folder", str(tmp_path), "--memory_bound", "2"]))
-    assert c.memory_bound == 5 and c.trajectory_batch == 2
+                               "--result_folder", str(tmp_path), "--memory_bound", "2", "--dead", "2"]))
+    assert c.memory_bound == 2 and c.trajectory_batch == 2 and c.memory_bound_given == 2
     d = m.preset(m.parse_args(["--note", "t", "--model_name", "stabilityai/stable-diffusion-2-1-base", "--dataset_name", "Examples",
                                "--result_folder", str(tmp_path), "--memory_bound=3", "--trajectory_batch", "8"]))
-    assert d.trajectory_batch == 3
+    assert d.trajectory_batch == 3 and d.memory_bound == 3
+    for bad in (["--memory_bound", "x"], ["--memory_bound", "0"], ["--memory_bound", "--other"]):       # argparse errors, not a bare ValueError / a silent 1
+        with pytest.raises(SystemExit):
+            m.parse_args(["--note", "t", "--model_name", "stabilityai/stable-diffusion-2-1-base"] + bad)
+    # the chunking and the guidance chains per call follow the explicit bound
+    from diffusion_pullback_amd import edit as E
+
+    class _Eng:
+        max_batch = 40
+
+    class _U:
+        engine = _Eng()
+    eb = E._EditBase()
+    eb.unet, eb.memory_bound, eb.trajectory_batch = _U(), c.memory_bound, c.trajectory_batch
+    assert [x.shape[0] for x in eb._chunks(torch.zeros(5, 1))] == [2, 2, 1]
     b = m.preset(m.parse_args(["--note", "u", "--model_name", "CelebA_HQ_HF", "--dataset_name", "CelebA_HQ", "--result_folder", str(tmp_path),
                                "--performance_boosting_t", "0.2", "--use_x_space_guidance", "True", "--h_t", "0.6"]))
     assert not b.is_stable_diffusion and b.memory_bound == 50 and b.x_space_guidance_scale == 4
@@ -347,3 +362,64 @@ def test_measurement_scripts_compile():
     assert len(files) > 10
     for f in files:
         py_compile.compile(f, doraise=True, cfile=os.path.join("/tmp", "dpb_pyc_" + os.path.basename(f) + "c"))
+
+
+def test_p8_isa_keeps_fragment_registers_untouched_until_their_wait(tmp_path):
+    """gemm_p8.hip reads its MFMA fragments with `asm volatile ds_read_b128` and orders them only by threading the registers through a later
+    `s_waitcnt lgkmcnt(0)` asm (csrc/gemm_p8.hip:44-58).  Nothing in the language stops a future compiler from placing a copy, a spill or a
+    consumer of a not-yet-landed fragment between the two; the bitwise / race-screen GPU tests cannot see that class of regression.  This check
+    reads the gfx950 ISA hipcc emits here (cross-compiles without a GPU): between every ds_read_b128 and the next lgkmcnt(0) wait no
+    instruction may name one of its destination registers, the kernels must not use scratch, and the counted DMA waits must be the ones the
+    schedule in the file header derives (two LDS-DMA pieces per stage: vmcnt(10) / vmcnt(6))."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    out = tmp_path / "gemm_p8.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
+                        os.path.join(root, "diffusion_pullback_amd", "csrc", "gemm_p8.hip"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    kernels = re.split(r"^(_ZN3dpb14gemm_p8_kernel\w+):", text, flags=re.M)[1:]
+    assert len(kernels) >= 2 * 4, "expected the gemm_p8_kernel instantiations"
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+    def regs(s):
+        o = set()
+        for m in reg.finditer(s):
+            if m.group(1) is not None:
+                o.add(int(m.group(1)))
+            else:
+                o.update(range(int(m.group(2)), int(m.group(3)) + 1))
+        return o
+    n_reads = 0
+    for name, body in zip(kernels[0::2], kernels[1::2]):
+        body = body.split(".Lfunc_end")[0]
+        assert "scratch_" not in body, name
+        lines = body.splitlines()
+        last_mfma = max(i for i, ln in enumerate(lines) if "v_mfma_" in ln.split(";")[0])
+        pending = set()
+        waits = []
+        for ln in lines[:last_mfma + 1]:          # the K loop: the epilogue behind it stages through LDS with the compiler's own (counted) waits
+            ins = ln.split(";")[0].strip()
+            if not ins or ins.startswith(".") or ins.endswith(":"):
+                continue
+            if ins.startswith("s_waitcnt"):
+                waits.append(ins)
+                if "lgkmcnt(0)" in ins:
+                    pending.clear()
+                continue
+            touched = regs(ins)
+            if ins.startswith("ds_read_b128"):
+                dst = regs(ins.split(",")[0])
+                assert not (touched - dst) & pending, (name, ins)          # its address register is not a pending fragment either
+                pending |= dst
+                n_reads += 1
+                continue
+            assert not touched & pending, f"{name}: `{ins}` names a fragment register before its s_waitcnt lgkmcnt(0)"
+        vm = [int(m) for w in waits for m in re.findall(r"vmcnt\((\d+)\)", w)]
+        assert vm.count(10) >= 2 and vm.count(6) >= 3, (name, sorted(set(vm)))   # two unrolled K tiles + the prologue (drains: prologue / epilogue only)
+    assert n_reads >= 8 * 2 * 24
+    for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", text):
+        assert m.group(1) == "0"
