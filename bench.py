@@ -517,11 +517,12 @@ def main():
         kinds = {"gemm_kernel<%s,64,64,4>" % tname: eng.profile_read(0), "gemm_kernel<%s,128,128,4>" % tname: eng.profile_read(1),
                  "gemm_dma_kernel<128,128,3> / <256,128,3>": eng.profile_read(2), "gemm_dma_kernel<64,64,4>": eng.profile_read(3),
                  "gemm_ring64_kernel<128,128,2>": eng.profile_read(4), "conv_halo_kernel": eng.profile_read(5),
-                 "gemm_ring64_kernel<256,256,2> (8 waves)": eng.profile_read(6), "gemm_p8_kernel (256x256, 8 waves, 8-phase)": eng.profile_read(11)}
+                 "gemm_ring64_kernel<256,256,2> (8 waves)": eng.profile_read(6), "gemm_p8_kernel (256x256, 8 waves, 8-phase)": eng.profile_read(11),
+                 "gemm_wres_kernel (weights-resident streaming, K = 320)": eng.profile_read(12)}
         attn = {"attention forward (flash)": eng.profile_read(7), "attention tangent (attn_jvp_kernel)": eng.profile_read(8),
                 "attention adjoint (query-major + key-major launches)": eng.profile_read(9), "cross-attention tangent / adjoint (attn_cross_kernel)": eng.profile_read(10)}
         ovh_ms = eng.profile_overhead_ms()
-        KIND_OF = dict(zip(kinds, (0, 1, 2, 3, 4, 5, 6, 11)))
+        KIND_OF = dict(zip(kinds, (0, 1, 2, 3, 4, 5, 6, 11, 12)))
         ATTN_OF = dict(zip(attn, (7, 8, 9, 10)))
         raw_ms = {n: eng.profile_read(1000 + c)[1] for n, c in list(KIND_OF.items()) + list(ATTN_OF.items())}   # unclamped raw bracket sums (kind + 1000)
         eng.profile(False)

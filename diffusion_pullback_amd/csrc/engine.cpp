@@ -175,7 +175,7 @@ int gemm(dpb_engine* e, GemmArgs a, bool can_defer = false) {
   int nl = 1;                                   // kernels enqueued: the product itself (+ splitk_reduce_kernel for split-K launches)
   if (!e->profiling) { const int r = launch_gemm(e->dtype, a, e->stream, &nl, pend); e->n_launch += nl; e->pend.on = pend && pend->splitk > 1; return r; }
   int kind;
-  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); kind = gemm_uses_halo(e->dtype, az) ? 5 : dm == 530 ? 11 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile, 11: 8-phase 256x256 tile (gemm_p8.hip)
+  { GemmArgs az = a; az.zeros = e->ws + e->zeros; const int dm = gemm_uses_dma(e->dtype, a); kind = gemm_uses_halo(e->dtype, az) ? 5 : dm == 540 ? 12 : dm == 530 ? 11 : dm == 518 ? 6 : dm >= 512 ? 4 : (dm == 128 || dm == 130 || dm == 132 || dm == 256) ? 2 : dm ? 3 : gemm_uses_big_tile(e->dtype, a); }   // 0: 64x64 register-staged, 2: 128x128 ring, 3: 64x64 ring, 4: BK=64 ring (128x128 tile), 5: halo-tile 3x3 convolution, 6: BK=64 ring, 256x256 tile, 11: 8-phase 256x256 tile (gemm_p8.hip)
   // the same bracket helpers as the attention launches (an event that cannot be created or recorded costs the bracket, never leaks its partner)
   const int pi = prof_open(e, 2.0 * a.M * (double)a.N * kk * a.Z1 * a.Z2, kind, a.M, a.N, a.K, a.Z1 * a.Z2, a.gather);
   int r = launch_gemm(e->dtype, a, e->stream, &nl, pend);
@@ -1292,7 +1292,7 @@ int dpb_engine_profile_read(dpb_engine* e, int big_tile, int64_t* count, double*
   *count = 0; *total_ms = 0; *flops = 0;
   const bool raw = big_tile >= 1000;                 // kind + 1000: the RAW bracket times (no empty-bracket correction, nothing clamped)
   if (raw) big_tile -= 1000;
-  if (big_tile < 0 || big_tile > 11) return fail("dpb_engine_profile_read: kind must be 0..11 or 1000..1011");
+  if (big_tile < 0 || big_tile > 12) return fail("dpb_engine_profile_read: kind must be 0..12 or 1000..1012");
   for (auto& p : e->prof) {
     if (p.big != big_tile) continue;
     float ms = 0;
@@ -1318,6 +1318,7 @@ int dpb_debug_set(const char* key, int value) {
   else if (!strcmp(key, "gemm_dma_auto")) { gemm_debug_dma_auto(value); return 0; }
   else if (!strcmp(key, "gemm_order")) { gemm_debug_order(value); return 0; }
   else if (!strcmp(key, "p8")) { gemm_debug_p8(value); return 0; }
+  else if (!strcmp(key, "wres")) { gemm_debug_wres(value); return 0; }
   else if (!strcmp(key, "gn_deterministic")) { gn_debug_deterministic(value); return 0; }
   else if (!strcmp(key, "graph_iterate")) { g_graph_iterate = value; return 0; }
   else if (!strcmp(key, "attn_shared")) { attn_debug_shared(value); return 0; }

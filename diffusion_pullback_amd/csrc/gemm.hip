@@ -447,6 +447,8 @@ void gemm_debug_set(int tile, int splitk, int kch) { g_force_tile = tile; g_forc
 void gemm_debug_dma_auto(int on) { g_dma_auto = on; }
 static int g_p8 = 1;
 void gemm_debug_p8(int on) { g_p8 = on; }
+static int g_wres = 1;
+void gemm_debug_wres(int on) { g_wres = on; }
 static thread_local int t_reduce_launched = 0;   // set by launch_t when a splitk_reduce_kernel launch followed the product
 static thread_local GemmArgs* t_pending = nullptr;   // launch_gemm(..., pending): where a deferrable reduction is parked instead of launched
 
@@ -485,6 +487,14 @@ static const ShapeOverride* find_override(const GemmArgs& a) {
   for (const auto& r : shape_overrides())
     if (r.M == a.M && r.N == a.N && r.K == a.K && r.gather == a.gather && a.Z1 * a.Z2 == 1) return &r;
   return nullptr;
+}
+
+// The weights-resident streaming kernel (gemm_wres.hip, tile code 540): plain products with K = 320 and N a multiple of 320 (the 320-channel linear layers
+// of the 64 x 64 level, tangent / adjoint passes) once every CU gets at least one 32-row tile.
+static int wres_wants(int dtype, const GemmArgs& a) {
+  static const int wres_env = getenv("DPB_WRES") ? atoi(getenv("DPB_WRES")) : 1;              // tuning switch (0: ring / 8-phase tiles as in round 5)
+  static const int min_m = getenv("DPB_WRES_MIN_M") ? atoi(getenv("DPB_WRES_MIN_M")) : 8192;  // tuning switch
+  return wres_env && g_wres && a.M >= min_m && gemm_wres_supported(dtype, a);
 }
 
 // The 8-phase 256 x 256 tile (gemm_p8.hip) takes a product when its tiles fill the chip (one 8-wave block per CU): >= 160 tiles; at most 25 % of the
@@ -534,12 +544,14 @@ int gemm_uses_dma(int dtype, const GemmArgs& a) {
   if (force >= 521 && force <= 523) return (a.gather == GATHER_NONE && a.epi == EPI_PLAIN) ? force : 515;
   if (force == 518) return a.gather == GATHER_NONE ? 518 : 515;
   if (force == 530) return ((a.epi == EPI_PLAIN || a.gather == GATHER_NONE) && (a.gather == GATHER_NONE || a.Cin % 64 == 0)) ? 530 : 515;
+  if (force == 540) return gemm_wres_supported(dtype, a) ? 540 : 515;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.Z1 * a.Z2;
   const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.Z1 * a.Z2;
   // measured on the path's layer shapes (profiles/r01_gemm_microbench.txt): the 128x128 ring wins once every CU holds
   // >= ~2 tiles, and for long-K under-filled problems when combined with split-K; short-K mid-size problems go to the
   // 64x64 ring; everything else (tiny problems, fp32, dual-operand products) to the register-staged kernel.
   if (!g_dma_auto || a.K < 256) return 0;
+  if (wres_wants(dtype, a)) return 540;
   if (p8_wants(dtype, a)) return 530;
   // 256x256 8-wave tile (half the L2->LDS bytes per flop): plain-row products that give >= 160 such tiles with < 7 % padding and K >= 640
   // -- 12-26 % ahead of the 128x128 ring there, behind it below (profiles/r02_gemm_big_microbench.txt, r02_gemm_split_microbench.txt)
@@ -606,7 +618,7 @@ int gemm_pick_splitk_dma(const GemmArgs& a, int tile) {
     // >= 192 tiles (3/4 of the CUs hold a block): splitting only pays for K >= 4096 and only two-fold -- measured per shape in
     // profiles/r02_gemm_split_microbench.txt (5120x640: K 1920 / 2560 24 / 32 us unsplit vs 34 / 41 us three-fold, K 5120 52 us two-fold vs
     // 58 unsplit; 1280x3840x1280 25 vs 36 us; 320x10240x1280 18 vs 25 us)
-    if (tile == 518 || tile == 530) return 1;  // one 8-wave block per CU and >= 160 tiles by construction: never split
+    if (tile == 518 || tile == 530 || tile == 540) return 1;  // one block per CU by construction: never split
     if (tiles >= 192) s = (tiles < 256 && nk >= 128) ? 2 : 1;
     else {
       s = std::max<long>(1, (target + tiles / 2) / tiles);
@@ -738,7 +750,7 @@ static int launch_t(int dtype, GemmArgs a, hipStream_t st) {
   if (pl.kind == PLAN_HALO) {
     if (int r = launch_conv_halo(a, st)) return r;
   } else if (pl.kind == PLAN_RING) {
-    if (int r = pl.tile >= 530 ? launch_gemm_p8(a, pl.tile, st) : pl.tile >= 512 ? launch_gemm_ring64(a, pl.tile, st) : launch_gemm_dma(a, pl.tile, st)) return r;
+    if (int r = pl.tile == 540 ? launch_gemm_wres(a, st) : pl.tile >= 530 ? launch_gemm_p8(a, pl.tile, st) : pl.tile >= 512 ? launch_gemm_ring64(a, pl.tile, st) : launch_gemm_dma(a, pl.tile, st)) return r;
   } else if (pl.kind == PLAN_REG128) {
     dim3 grid(((a.M + 127) / 128) * ((a.N + 127) / 128), Z, a.splitk);
     launch_reg_t<T, 128, 128, 4>(a, grid, st);

@@ -69,6 +69,9 @@ int gemm_uses_dma(int dtype, const GemmArgs& a);   // 0 = register-staged kernel
 void gemm_debug_dma_auto(int on);
 void gn_debug_deterministic(int on);
 int gn_deterministic();
+bool gemm_wres_supported(int dtype, const GemmArgs& a);                // weights-resident streaming kernel (gemm_wres.hip, tile code 540): K = 320, N % 320 == 0, plain epilogue
+int launch_gemm_wres(const GemmArgs& a, hipStream_t st);
+void gemm_debug_wres(int on);   // 1 (default): the dispatch may pick the weights-resident kernel; 0: round-5 dispatch, bitwise A/B
 void gemm_debug_p8(int on);     // 1 (default): the dispatch may pick the 8-phase tile; 0: round-4 dispatch (rings / halo kernel), bitwise A/B
 void gemm_debug_order(int o);   // -1 heuristic, 0 A-major, 1 B-major
 int gemm_pick_splitk_dma(const GemmArgs& a, int tile);   // tuning overrides for micro-benchmarks (0 = heuristic)   // 1: 128x128 tile instantiation, 0: 64x64

@@ -156,12 +156,13 @@ int dpb_engine_stats(const dpb_engine* e, int64_t* launches, double* gemm_flops,
  * events on the engine's stream; _read synchronises and sums the launches of one GEMM kernel kind: count, total
  * milliseconds, algorithmic flops.  kind: 0 register-staged 64x64, 1 register-staged 128x128, 2 BK=32 ring 128x128 /
  * 256x128, 3 BK=32 ring 64x64, 4 BK=64 ring with 128-column tiles (gemm_ring64.hip), 5 halo-tile 3x3 convolution (gemm_halo.hip), 6 BK=64 ring
- * with the 256x256 tile, 11 the 8-phase 256x256 tile (gemm_p8.hip: two wave groups alternating between load and matrix segments, counted vmcnt);
+ * with the 256x256 tile, 11 the 8-phase 256x256 tile (gemm_p8.hip: two wave groups alternating between load and matrix segments, counted vmcnt), 12 the
+ * weights-resident streaming kernel of the K = 320 linear layers (gemm_wres.hip: weight slice in registers, activation rows streamed through an LDS ring);
  * attention (algorithmic flops = 2 / 5 / 7 L x L x d products per head and sample / tangent / cotangent): 7 flash forward,
  * 8 fused self-attention tangent, 9 fused self-attention adjoint (its query-major and key-major launches in ONE bracket; the CSV's `gather`
  * column holds the route: bit 0 multi-cotangent query-major kernel, bit 1 shared-probability key-major kernel), 10 one-launch cross-attention
  * tangent (gather 0) / adjoint (gather 1): 2 L x 77 x d products.  kind + 1000 returns the RAW bracket times of that kind (without the empty-bracket
- * correction of dpb_engine_profile_overhead, which clamps a bracket shorter than the correction to 0); any other kind (neither 0..11 nor 1000..1011) fails.
+ * correction of dpb_engine_profile_overhead, which clamps a bracket shorter than the correction to 0); any other kind (neither 0..12 nor 1000..1012) fails.
  * _dump writes one CSV line per recorded bracket. */
 int dpb_engine_profile(dpb_engine* e, int enable);
 int dpb_engine_profile_read(dpb_engine* e, int kind, int64_t* count, double* total_ms, double* flops);
@@ -170,9 +171,9 @@ int dpb_engine_profile_dump(dpb_engine* e, const char* csv_path);
  * this returns that correction so that the raw bracket times can be reconstructed (raw = reported + overhead per launch). */
 int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms);
 /* Tuning overrides for micro-benchmarks and the bitwise kernel-equivalence tests (0 / -1 = heuristic): "gemm_tile"
- * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands, 530 = the 8-phase 256x256 tile (gemm_p8.hip), 521 / 522 / 523 =
+ * (64, 128: register-staged; 129, 131, 133, 257, 65, 67: BK=32 rings; 512..518: BK=64 rings, 518 = 256x256 tile for plain-row operands, 530 = the 8-phase 256x256 tile (gemm_p8.hip), 540 = the weights-resident streaming kernel (gemm_wres.hip; products it does not take fall back to 515), 521 / 522 / 523 =
  * half tiles 64x128 (3 / 2 stages) and 128x64 for plain-row operands;
- * 600: halo-tile 3x3 convolution), "gemm_splitk" (n), "gemm_kch", "p8" (1, default: the dispatch may pick the 8-phase tile; 0 = the ring / halo dispatch of round 4), "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block
+ * 600: halo-tile 3x3 convolution), "gemm_splitk" (n), "gemm_kch", "p8" (1, default: the dispatch may pick the 8-phase tile; 0 = the ring / halo dispatch of round 4), "wres" (1, default: K = 320 / N % 320 == 0 plain products of >= 8192 rows go to the weights-resident kernel; 0 = the round-5 dispatch; bitwise equal), "gemm_dma_auto" (0|1), "gemm_order" (-1 | 0 A-major | 1 B-major block
  * order per XCD), "gn_deterministic" (1, default: GroupNorm statistics of the two-pass kernels reduced in a fixed order -> bitwise
  * reproducible runs; 0 = the round-1 atomic statistics, A/B only), "graph_iterate" (0|1: dpb_pullback_iterate replays a captured hipGraph on a non-default stream;
  * measured equal to eager launches, default 0), "attn_shared" (2, default: shared-probability key-major adjoint of the head-dim-40
@@ -183,7 +184,7 @@ int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms
  * ONE launch; 0 = GEMM + softmax + transpose + GEMM), "geglu_fwd" (1, default: dpb_forward applies GEGLU in the epilogue of the unsplit FF-in products), "iter_alias" (1, default: inside dpb_pullback_iterate the tap's
  * tangent passes from the tangent to the adjoint pass on the device, U is written by the last iteration only; 0 = fp32 round trip through U every iteration; bitwise equal).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
- * kernel and split count per product shape; DPB_P8 (0: no 8-phase tile), DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
+ * kernel and split count per product shape; DPB_P8 (0: no 8-phase tile), DPB_WRES (0: no weights-resident kernel), DPB_WRES_MIN_M, DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
  * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_LN_FUSE, DPB_LAZY_REDUCE, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_SHARED, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L,
  * DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN, DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants; DPB_GEMM_TRACE=1 prints every
  * product and synchronises after it (debugging). */

@@ -326,6 +326,59 @@ def test_p8_gemm_bitwise_equals_ring_gemm_and_race_screen():
         L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
 
 
+def test_wres_gemm_bitwise_equals_ring_gemm_and_race_screen():
+    """The weights-resident streaming kernel (gemm_wres.hip, tile code 540) takes the K = 320 linear layers of the 64 x 64 level in the tangent / adjoint passes
+    (plain epilogue, at most one 16-bit row operand).  It issues the same K16 MFMA sequence per output element as the BK = 64 ring (515) and the same epilogue
+    arithmetic: tangents and cotangents must agree BIT FOR BIT -- N = 320 and 960 (three column slices), M from fewer tiles than CUs to 20480 rows, ragged M
+    (M % 32 != 0), residual (tangent) and accumulate (adjoint) operands, f16.  Its LDS ring and the per-wave operand slabs are ordered by hand-counted vmcnt
+    + one barrier per tile only, so three sizes are repeated 25 times against the first run as a race screen."""
+    from diffusion_pullback_amd import lib as L
+    from diffusion_pullback_amd.engine import Engine
+    from diffusion_pullback_amd.tape import Tape
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+
+    def engine(H, cin, cout, dtype, batch, res=False):
+        p = {"c.weight": torch.randn(cout, cin, 1, 1, generator=g) * 0.05, "c.bias": torch.randn(cout, generator=g)}
+        t = Tape(p, dtype, _dev())
+        t.temb_in = t.buf(1, 8, L.BUF_SHARED)
+        t.x = t.buf(H * H, cin)
+        o = t.conv("c", t.x, (H, H), cout, ks=1, stride=1, pad=0, res=t.x if res else -1)
+        t.tap("o", o, cout, H, H)
+        return Engine(t, 8, False, True, cin, max_batch=batch, max_tangents=batch)
+
+    # (H, cout, batch, res): M = batch * H * H rows; cout = 960 -> the adjoint product has K = 960 and stays on the ring in both arms
+    cases = [(64, 320, 5, False), (64, 320, 5, True), (64, 960, 2, False), (20, 320, 3, True), (12, 320, 1, False), (10, 320, 7, True), (64, 320, 1, True)]
+    try:
+        for dtype in (torch.bfloat16, torch.float16):
+            for (H, cout, batch, res) in (cases if dtype == torch.bfloat16 else cases[1:4]):
+                e = engine(H, 320, cout, dtype, batch, res)
+                x = torch.randn(batch, 320, H, H, generator=g).cuda()
+                V = torch.randn(batch, 320 * H * H, generator=g).cuda()
+                U = torch.randn(batch, cout * H * H, generator=g).cuda()
+                outs = {}
+                for tile in (515, 540):
+                    L.check(lib.dpb_debug_set(b"gemm_splitk", 1)); L.check(lib.dpb_debug_set(b"gemm_tile", tile))
+                    e.primal(x, 1.0, None, "o")
+                    outs[tile] = (e.jvp("o", V).clone(), e.vjp("o", U).clone())
+                for a, b, name in zip(outs[515], outs[540], ("jvp", "vjp")):
+                    assert torch.isfinite(b).all() and torch.equal(a, b), f"{dtype} case {(H, cout, batch, res)} {name}: max |d| = {(a - b).abs().max().item():.3e}"
+                del e
+        for (H, batch, res) in [(64, 5, True), (64, 2, False), (36, 3, True)]:
+            e = engine(H, 320, 320, torch.bfloat16, batch, res)
+            x = torch.randn(batch, 320, H, H, generator=g).cuda()
+            V = torch.randn(batch, 320 * H * H, generator=g).cuda()
+            U = torch.randn(batch, 320 * H * H, generator=g).cuda()
+            L.check(lib.dpb_debug_set(b"gemm_splitk", 1)); L.check(lib.dpb_debug_set(b"gemm_tile", 540))
+            e.primal(x, 1.0, None, "o")
+            first = (e.jvp("o", V).clone(), e.vjp("o", U).clone())
+            for rep in range(25):
+                assert torch.equal(e.jvp("o", V), first[0]) and torch.equal(e.vjp("o", U), first[1]), f"run {rep} of {(H, batch, res)} differs from the first: a staging race"
+            del e
+    finally:
+        L.check(lib.dpb_debug_set(b"gemm_tile", 0)); L.check(lib.dpb_debug_set(b"gemm_splitk", 0))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_p8_dispatch_is_bitwise_the_ring_dispatch_on_a_network(dtype):
     """Inside a network (two-level SD-shaped U-Net, 64 x 64 latents, 5 tangents) the dispatch sends the FF-in / FF-out products of the 32 x 32 level --

@@ -36,7 +36,7 @@ def label(name):
 def kind_of(name):
     """kernel-trace name -> the GEMM kernel kind of dpb_engine_profile_read (include/dpb.h), or None"""
     name = re.sub(r"^void\s+", "", name).replace("dpb::", "").replace(" ", "")
-    m = re.match(r"(gemm_kernel|gemm_dma_kernel|gemm_ring64_kernel|conv_halo_kernel|gemm_p8_kernel)<(.*)>", name)
+    m = re.match(r"(gemm_kernel|gemm_dma_kernel|gemm_ring64_kernel|conv_halo_kernel|gemm_p8_kernel|gemm_wres_kernel)<(.*)>", name)
     if not m:
         return None
     fam, par = m.group(1), m.group(2).split(",")
@@ -46,7 +46,7 @@ def kind_of(name):
         return 3 if par[0] == "64" else 2
     if fam == "gemm_ring64_kernel":
         return 6 if par[0] == "256" and par[1] == "256" else 4
-    return 5 if fam == "conv_halo_kernel" else 11
+    return 5 if fam == "conv_halo_kernel" else 12 if fam == "gemm_wres_kernel" else 11
 
 
 def trace_by_kind(path):

@@ -19,7 +19,7 @@ PMC_ITERS = float(sys.argv[5]) if len(sys.argv) > 5 else 12.0
 DTYPE = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 TITLE = sys.argv[7] if len(sys.argv) > 7 else "SD-1.5 mid-block, k = 5, bf16, one power iteration"
 PEAK_TF, PEAK_HBM = {"fp32": 157.3}.get(DTYPE, 2500.0), 8.0        # dense MFMA TFLOP/s of the dtype, HBM TB/s (MI355X_MICROARCH.md)
-KIND = {"0": "gemm_kernel", "1": "gemm_kernel", "2": "gemm_dma_kernel", "3": "gemm_dma_kernel", "4": "gemm_ring64_kernel", "5": "conv_halo_kernel", "6": "gemm_ring64_kernel", "11": "gemm_p8_kernel"}
+KIND = {"0": "gemm_kernel", "1": "gemm_kernel", "2": "gemm_dma_kernel", "3": "gemm_dma_kernel", "4": "gemm_ring64_kernel", "5": "conv_halo_kernel", "6": "gemm_ring64_kernel", "11": "gemm_p8_kernel", "12": "gemm_wres_kernel"}
 
 
 def family(name):
@@ -52,7 +52,7 @@ def main():
     flops, gemm_fams = {}, set()
     for r in csv.DictReader(open(os.path.join(DIR, n_csv))):
         big, mnkz = int(r["big"]), 2.0 * float(r["M"]) * float(r["N"]) * float(r["K"]) * float(r["Z"])
-        if big <= 6 or big == 11:
+        if big <= 6 or big in (11, 12):
             f = KIND.get(r["big"], "gemm_kernel")
             flops[f] = flops.get(f, 0.0) + mnkz
             gemm_fams.add(f)
@@ -93,7 +93,7 @@ def main():
     # per-shape binding roof of the product launches: time at the MFMA peak vs time to move the unique operand bytes at the HBM peak
     shapes = {}
     for r in csv.DictReader(open(os.path.join(DIR, n_csv))):
-        if int(r["big"]) > 6 and int(r["big"]) != 11:
+        if int(r["big"]) > 6 and int(r["big"]) not in (11, 12):
             continue
         M, N, K, Z, g = int(r["M"]), int(r["N"]), int(r["K"]), int(r["Z"]), int(r["gather"])
         kin = K // 9 if g in (1, 2, 3) and K % 9 == 0 and K > 72 else K              # 3x3 convolutions read each input pixel once, not nine times
