@@ -490,11 +490,15 @@ static const ShapeOverride* find_override(const GemmArgs& a) {
 }
 
 // The weights-resident streaming kernel (gemm_wres.hip, tile code 540): plain products with K = 320 and N a multiple of 320 (the 320-channel linear layers
-// of the 64 x 64 level, tangent / adjoint passes) once every CU gets at least one 32-row tile.
+// of the 64 x 64 level, tangent / adjoint passes) from the row count at which streaming beats the tile kernels.  Measured against the round-5 dispatch per
+// shape (profiles/r06_wres_shapes.txt, event brackets, same session): N = 320 -- 20480 rows 15.0 vs 11.8 us (the 200 KB weight preload per CU and three
+// serial tiles are not amortised: the rings keep the 5-tangent pass), 40960 rows equal, 81920 rows 30 vs 35 us, 327680 rows 93 vs 156 us (4.5 TB/s of
+// operand traffic, 6.7 with a row operand); N = 960 (three column slices re-stream A) -- ahead only at 327680 rows (273 vs 359 us).
 static int wres_wants(int dtype, const GemmArgs& a) {
   static const int wres_env = getenv("DPB_WRES") ? atoi(getenv("DPB_WRES")) : 1;              // tuning switch (0: ring / 8-phase tiles as in round 5)
-  static const int min_m = getenv("DPB_WRES_MIN_M") ? atoi(getenv("DPB_WRES_MIN_M")) : 8192;  // tuning switch
-  return wres_env && g_wres && a.M >= min_m && gemm_wres_supported(dtype, a);
+  static const int min_m = getenv("DPB_WRES_MIN_M") ? atoi(getenv("DPB_WRES_MIN_M")) : 49152; // tuning switch: rows from which the N = 320 products take it
+  if (!wres_env || !g_wres || !gemm_wres_supported(dtype, a)) return 0;
+  return a.M >= (a.N == 320 ? (long)min_m : 3L * min_m);
 }
 
 // The 8-phase 256 x 256 tile (gemm_p8.hip) takes a product when its tiles fill the chip (one 8-wave block per CU): >= 160 tiles; at most 25 % of the

@@ -174,7 +174,11 @@ __global__ __launch_bounds__(320) void gemm_wres_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    // ---- wave-local epilogue: stage, then 4 items per lane (row 8 u + (lane >> 3), 8 columns): alpha, + operand, 16-byte store
+    // ---- wave-local epilogue: stage, then 4 items per lane (row 8 u + (lane >> 3), 8 columns): alpha, + operand, 16-byte store.
+    // The staging writes are inline asm: hipcc's hazard recogniser does not pad an asm statement, and an LDS instruction that reads a VGPR an MFMA is
+    // still writing gets the OLD value (the first two writes after the last MFMA did: rows 0, 1, 4, 5 of every tile, run-to-run different) -- the wait
+    // states of the longest XDL write -> LDS-data read hazard are spent here by hand (cdna_hip_programming.md 5.7).
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
     static_for<0, 2>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       static_for<0, 16>([&](auto rc) {

@@ -215,8 +215,8 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
                         if tile == 518:
                             t256 = -(-M // 256) * -(-N // 256)
                             assert s == 1 and K >= 640 and t256 >= 160 and t256 * 65536 <= 1.07 * M * N, (M, N, K, s)
-                        if tile == 540:                                   # weights-resident streaming kernel: K = 320 linear layers once every CU has a 32-row tile
-                            assert dt != L.DPB_F32 and s == 1 and K == 320 and N % 320 == 0 and M >= 8192, (M, N, K, s)
+                        if tile == 540:                                   # weights-resident streaming kernel: K = 320 linear layers from the row count at which streaming the activations past resident weights beats the tile kernels
+                            assert dt != L.DPB_F32 and s == 1 and K == 320 and N % 320 == 0 and M >= (49152 if N == 320 else 147456), (M, N, K, s)
                             n_wres += 1
                         if tile == 530:                                   # 8-phase tile: fills the chip, <= 25 % padding (40 % from 2048 tiles on), last round >= 58 % occupied, unsplit
                             t256 = -(-M // 256) * -(-N // 256)
@@ -235,11 +235,12 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
                     if tile == 530:                                       # the 8-phase tile as an implicit-GEMM convolution: whole 64-channel K tiles
                         assert cin % 64 == 0 and s == 1 and M * cout >= 0.75 * (-(-M // 256) * -(-cout // 256)) * 65536
                         n_p8 += 1
-    assert n_plans > 4000 and n_p8 > 100 and n_wres >= 12
-    # the 320-channel linear layers of the 64x64 level (tangent / adjoint passes, plain epilogue): the weights-resident kernel, never split; not below
-    # 8192 rows, not with a fused epilogue, not for the 640-channel level
-    assert plan(L.DPB_BF16, 20480, 320, 320) == (2, 540, 1) and plan(L.DPB_F16, 327680, 960, 320) == (2, 540, 1)
-    assert plan(L.DPB_BF16, 4096, 320, 320)[1] != 540 and plan(L.DPB_BF16, 20480, 640, 640)[1] != 540 and plan(L.DPB_BF16, 20480, 2560, 320, epi=1)[1] != 540
+    assert n_plans > 4000 and n_p8 > 100 and n_wres >= 4
+    # the 320-channel linear layers of the 64x64 level (tangent / adjoint passes, plain epilogue) at many tangents: the weights-resident kernel, never split;
+    # not at 5 tangents (20480 rows: the rings are ahead), not with a fused epilogue, not for the 640-channel level
+    assert plan(L.DPB_BF16, 81920, 320, 320) == (2, 540, 1) and plan(L.DPB_F16, 327680, 960, 320) == (2, 540, 1)
+    assert plan(L.DPB_BF16, 20480, 320, 320)[1] != 540 and plan(L.DPB_BF16, 81920, 960, 320)[1] != 540
+    assert plan(L.DPB_BF16, 81920, 640, 640)[1] != 540 and plan(L.DPB_BF16, 327680, 2560, 320, epi=1)[1] != 540
     # the launch that overflowed: now the 256x256 tile, unsplit; and the same product forced onto the 128x128 ring keeps within the scratch
     assert plan(L.DPB_BF16, 10240, 1280, 5120) == (2, 530, 1)
     assert plan(L.DPB_BF16, 20480, 320, 2880, 64, 320)[0] == 3            # N = 320 (37.5 % padding on 256-column tiles): the halo-tile kernel keeps the 64x64-level convolutions
