@@ -26,6 +26,9 @@ namespace dpb {
 #ifndef DPB_ATT_ABL
 #define DPB_ATT_ABL 0     // measurement-only builds (make ablate_attn, tools/gpu_attn_ablate.sh; WRONG results): bit 0 drops a quarter of the head-dim-side MFMAs of the
 #endif                    // d = 40 kernels (what 16x16x32 tiles would save), bit 1 one of the six dS MFMAs of the tangent kernel (a stacked [K | dK] product), bit 2 the exp
+#ifndef DPB_OUT_STORE_ATT
+#define DPB_OUT_STORE_ATT 0   // flavour of the 8-byte output stores of the fused attention kernels (common.h store_out8): 0 plain, 1 sc1, 2 nt (A/B builds)
+#endif
 #define DPB_ATT_PAD 8     // row padding (bf16 elements) of the LDS [row][d] tiles (16 / 24 measured in round 3: 9.02 / 9.28 vs 8.99 ms per iteration)
 
 constexpr int att_waves(int d) { return d > 80 ? 4 : 8; }   // waves per block: 8 x 32 = 256 outer rows share every streamed tile
@@ -261,7 +264,7 @@ __global__ __launch_bounds__((FA<D, W>::NT)) void attn_fwd_kernel(FusedArgs a, b
     for (int g = 0; g < 4; ++g) {
       const int col = d * 32 + 8 * g + 4 * lhi;
       if (col < D && live) {
-        *reinterpret_cast<uint2*>(Op + col) = make_uint2(H16<FL>::pack2(acc[d][g * 4] * il, acc[d][g * 4 + 1] * il),
+        store_out8<DPB_OUT_STORE_ATT>(Op + col, H16<FL>::pack2(acc[d][g * 4] * il, acc[d][g * 4 + 1] * il),
                                                          H16<FL>::pack2(acc[d][g * 4 + 2] * il, acc[d][g * 4 + 3] * il));
       }
     }
@@ -407,7 +410,7 @@ __global__ __launch_bounds__((FA<D, W>::NT), (W == 4 && D <= 40 ? 2 : 1)) void a
           float v0 = acc[d][g * 4 + 2 * i] - delta * o0, v1 = acc[d][g * 4 + 2 * i + 1] - delta * o1;
           w[i] = H16<FL>::pack2(v0, v1);
         }
-        *reinterpret_cast<uint2*>(dOp + col) = make_uint2(w[0], w[1]);
+        store_out8<DPB_OUT_STORE_ATT>(dOp + col, w[0], w[1]);
       }
     }
 }
@@ -496,8 +499,7 @@ __global__ __launch_bounds__(FA<D>::NT) void attn_adj_q_kernel(FusedArgs a) {
           v[0] += H16<FL>::lo(ov.x); v[1] += H16<FL>::hi(ov.x);
           v[2] += H16<FL>::lo(ov.y); v[3] += H16<FL>::hi(ov.y);
         }
-        *reinterpret_cast<uint2*>(gQp + col) =
-            make_uint2(H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
+        store_out8<DPB_OUT_STORE_ATT>(gQp + col, H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
       }
     }
 }
@@ -634,8 +636,7 @@ __global__ __launch_bounds__(256) void attn_adj_q_multi_kernel(FusedArgs a) {
             v[0] += H16<FL>::lo(ov.x); v[1] += H16<FL>::hi(ov.x);
             v[2] += H16<FL>::lo(ov.y); v[3] += H16<FL>::hi(ov.y);
           }
-          *reinterpret_cast<uint2*>(gQp + col) =
-              make_uint2(H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
+          store_out8<DPB_OUT_STORE_ATT>(gQp + col, H16<FL>::pack2(v[0], v[1]), H16<FL>::pack2(v[2], v[3]));
         }
       }
   }
@@ -748,10 +749,8 @@ __global__ __launch_bounds__((FA<D, W>::NT), (D <= 40 ? 2 : 1)) void attn_adj_kv
           vv[0] += H16<FL>::lo(ov.x); vv[1] += H16<FL>::hi(ov.x);
           vv[2] += H16<FL>::lo(ov.y); vv[3] += H16<FL>::hi(ov.y);
         }
-        *reinterpret_cast<uint2*>(gKp + col) =
-            make_uint2(H16<FL>::pack2(vk[0], vk[1]), H16<FL>::pack2(vk[2], vk[3]));
-        *reinterpret_cast<uint2*>(gVp + col) =
-            make_uint2(H16<FL>::pack2(vv[0], vv[1]), H16<FL>::pack2(vv[2], vv[3]));
+        store_out8<DPB_OUT_STORE_ATT>(gKp + col, H16<FL>::pack2(vk[0], vk[1]), H16<FL>::pack2(vk[2], vk[3]));
+        store_out8<DPB_OUT_STORE_ATT>(gVp + col, H16<FL>::pack2(vv[0], vv[1]), H16<FL>::pack2(vv[2], vv[3]));
       }
     }
 }
@@ -986,8 +985,8 @@ __global__ __launch_bounds__((SHK<D, TJ>::NT)) void attn_adj_kv_shared_kernel(Fu
           vv[0] += H16<FL>::lo(ov.x); vv[1] += H16<FL>::hi(ov.x);
           vv[2] += H16<FL>::lo(ov.y); vv[3] += H16<FL>::hi(ov.y);
         }
-        *reinterpret_cast<uint2*>(gKp + col) = make_uint2(H16<FL>::pack2(vk[0], vk[1]), H16<FL>::pack2(vk[2], vk[3]));
-        *reinterpret_cast<uint2*>(gVp + col) = make_uint2(H16<FL>::pack2(vv[0], vv[1]), H16<FL>::pack2(vv[2], vv[3]));
+        store_out8<DPB_OUT_STORE_ATT>(gKp + col, H16<FL>::pack2(vk[0], vk[1]), H16<FL>::pack2(vk[2], vk[3]));
+        store_out8<DPB_OUT_STORE_ATT>(gVp + col, H16<FL>::pack2(vv[0], vv[1]), H16<FL>::pack2(vv[2], vv[3]));
       }
     }
 }

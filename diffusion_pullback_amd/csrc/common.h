@@ -62,6 +62,38 @@ template <> struct TT<f16> {
   __device__ static inline void st(f16* p, float v) { p->v = f2h(v); }
 };
 
+// How the 16-byte OUTPUT stores of the kernels leave the CU (round 6).  A plain store leaves its line dirty in the XCD's L2 and the kernel boundary writes
+// every dirty line back before the dependent launch starts (MI355X_MICROARCH.md price list, row "boundary": + B / 6 TB/s for B dirty bytes -- 2 us behind a
+// 13 MB activation of the 64 x 64 level, at ~335 boundaries per power iteration).  `sc1` stores are written through while the kernel runs, so the boundary has
+// nothing left to flush: same-session A/B on the headline 114.6 -> 120.4 iterations/s (+5.0 %; `nt` +3.4 %), profiles/r06_out_store_ab.txt.  Values are
+// unchanged (a store flavour, not an arithmetic change).  DPB_OUT_STORE: 1 sc1 (default) | 0 plain | 2 nt | 3 sc0 sc1 -- the A/B builds of tools/build_variant.sh.
+// Inline asm because no builtin carries cache bits on a flat global store; the trailing s_nop 1 keeps hipcc's next instruction from overwriting the data
+// registers before the store has read them (cdna_hip_programming.md 5.7 item 1).  The data always comes from a VALU conversion, never straight from an MFMA.
+#ifndef DPB_OUT_STORE
+#define DPB_OUT_STORE 1
+#endif
+#ifndef DPB_OUT_STORE_F32
+#define DPB_OUT_STORE_F32 0       // the same for 16-byte fp32 stores (split-K slabs, fp32 engines): A/B only
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+template <int MODE>
+__device__ __forceinline__ void store_out16(void* p, u32x4_ v) {
+  if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");   // (A/B only: without the pad)
+  else if constexpr (MODE == 5) *(volatile __attribute__((address_space(1))) u32x4_*)(p) = v;                                            // hipcc's own `sc0 sc1` store (hazards padded by the compiler)
+  else *reinterpret_cast<u32x4_*>(p) = v;
+}
+template <int MODE>
+__device__ __forceinline__ void store_out8(void* p, unsigned a, unsigned b) {     // 8-byte form (attention outputs: row-per-lane fragments)
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+  u32x2_ v = {a, b};
+  if constexpr (MODE == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (MODE == 2) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<u32x2_*>(p) = v;
+}
+
 // 16-byte vector load/store <-> float[CH]
 template <typename T> struct Vec;
 template <> struct Vec<float> {
@@ -71,7 +103,12 @@ template <> struct Vec<float> {
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
   }
   __device__ static inline void store(float* p, const float* o) {
-    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (DPB_OUT_STORE_F32 != 0) {
+      u32x4_ v = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+      store_out16<DPB_OUT_STORE_F32>(p, v);
+    } else {
+      *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 };
 template <> struct Vec<bf16> {
@@ -90,7 +127,7 @@ template <> struct Vec<bf16> {
     v8 r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (__bf16)o[i];          // 4 x v_cvt_pk_bf16_f32
-    *reinterpret_cast<v8*>(p) = r;
+    store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r));
   }
 };
 
@@ -106,7 +143,7 @@ template <> struct Vec<f16> {
     v8 r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (_Float16)o[i];          // 4 x v_cvt_pk_f16_f32
-    *reinterpret_cast<v8*>(p) = r;
+    store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r));
   }
 };
 
