@@ -85,6 +85,14 @@ __device__ __forceinline__ void store_out16(void* p, u32x4_ v) {
   else if constexpr (MODE == 5) *(volatile __attribute__((address_space(1))) u32x4_*)(p) = v;                                            // hipcc's own `sc0 sc1` store (hazards padded by the compiler)
   else *reinterpret_cast<u32x4_*>(p) = v;
 }
+#ifndef DPB_WT_MIN
+#define DPB_WT_MIN 0          // outputs of fewer elements than this keep plain stores (their lines stay in the producing XCD's L2 for a same-XCD reader); A/B builds
+#endif
+template <int MODE>
+__device__ __forceinline__ void store_out16(void* p, u32x4_ v, bool wt) {
+  if (wt) store_out16<MODE>(p, v);
+  else *reinterpret_cast<u32x4_*>(p) = v;
+}
 template <int MODE>
 __device__ __forceinline__ void store_out8(void* p, unsigned a, unsigned b) {     // 8-byte form (attention outputs: row-per-lane fragments)
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
@@ -98,6 +106,7 @@ __device__ __forceinline__ void store_out8(void* p, unsigned a, unsigned b) {   
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
+  __device__ static inline void store(float* p, const float* o, bool) { store(p, o); }
   __device__ static inline void load(const float* p, float* o) {
     float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -129,6 +138,13 @@ template <> struct Vec<bf16> {
     for (int i = 0; i < 8; ++i) r[i] = (__bf16)o[i];          // 4 x v_cvt_pk_bf16_f32
     store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r));
   }
+  __device__ static inline void store(bf16* p, const float* o, bool wt) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    v8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)o[i];
+    store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r), wt);
+  }
 };
 
 template <> struct Vec<f16> {
@@ -144,6 +160,12 @@ template <> struct Vec<f16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (_Float16)o[i];          // 4 x v_cvt_pk_f16_f32
     store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r));
+  }
+  __device__ static inline void store(f16* p, const float* o, bool wt) {
+    v8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (_Float16)o[i];
+    store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r), wt);
   }
 };
 
@@ -197,6 +219,7 @@ template <> struct H16<0> {
   __device__ static inline f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   __device__ static inline void load8(const bf16* p, float* o) { Vec<bf16>::load(p, o); }
   __device__ static inline void store8(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
+  __device__ static inline void store8(bf16* p, const float* o, bool wt) { Vec<bf16>::store(p, o, wt); }
   __device__ static inline bf16x8 pack8(const float* x) {
     bf16x8 r;
 #pragma unroll
@@ -220,6 +243,7 @@ template <> struct H16<1> {
   }
   __device__ static inline void load8(const bf16* p, float* o) { Vec<f16>::load(reinterpret_cast<const f16*>(p), o); }
   __device__ static inline void store8(bf16* p, const float* o) { Vec<f16>::store(reinterpret_cast<f16*>(p), o); }
+  __device__ static inline void store8(bf16* p, const float* o, bool wt) { Vec<f16>::store(reinterpret_cast<f16*>(p), o, wt); }
   __device__ static inline bf16x8 pack8(const float* x) {
     f16x8 r;
 #pragma unroll

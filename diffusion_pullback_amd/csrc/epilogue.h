@@ -286,6 +286,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
     }
     return;
   }
+  const bool wt = (long)p.M * p.N >= DPB_WT_MIN;
   if (p.vec_ok && n + 8 <= p.N) {
     // The operands of the epilogue (row bias, residual, the value accumulated so far) do not depend on the product: the loads of up to four items
     // are issued together, at clamped rows, before anything waits -- one memory round trip per batch instead of one per operand and item (the
@@ -334,7 +335,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t8[e];
         }
-        H16<FL>::store8(C + (long)m * p.ldc + n, v);
+        H16<FL>::store8(C + (long)m * p.ldc + n, v, wt);
       }
     }
   } else {
