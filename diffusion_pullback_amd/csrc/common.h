@@ -65,7 +65,7 @@ template <> struct TT<f16> {
 // How the 16-byte OUTPUT stores of the kernels leave the CU (round 6).  A plain store leaves its line dirty in the XCD's L2 and the kernel boundary writes
 // every dirty line back before the dependent launch starts (MI355X_MICROARCH.md price list, row "boundary": + B / 6 TB/s for B dirty bytes -- 2 us behind a
 // 13 MB activation of the 64 x 64 level, at ~335 boundaries per power iteration).  `sc1` stores are written through while the kernel runs, so the boundary has
-// nothing left to flush: same-session A/B on the headline 114.6 -> 120.4 iterations/s (+5.0 %; `nt` +3.4 %), profiles/r06_out_store_ab.txt.  Values are
+// nothing left to flush: same-session A/Bs on the headline +0.8 ... +5.0 % depending on the box (`nt` less), profiles/r06_out_store_ab.txt.  Values are
 // unchanged (a store flavour, not an arithmetic change).  DPB_OUT_STORE: 1 sc1 (default) | 0 plain | 2 nt | 3 sc0 sc1 -- the A/B builds of tools/build_variant.sh.
 // Inline asm because no builtin carries cache bits on a flat global store; the trailing s_nop 1 keeps hipcc's next instruction from overwriting the data
 // registers before the store has read them (cdna_hip_programming.md 5.7 item 1).  The data always comes from a VALU conversion, never straight from an MFMA.
@@ -85,14 +85,6 @@ __device__ __forceinline__ void store_out16(void* p, u32x4_ v) {
   else if constexpr (MODE == 5) *(volatile __attribute__((address_space(1))) u32x4_*)(p) = v;                                            // hipcc's own `sc0 sc1` store (hazards padded by the compiler)
   else *reinterpret_cast<u32x4_*>(p) = v;
 }
-#ifndef DPB_WT_MIN
-#define DPB_WT_MIN 0          // outputs of fewer elements than this keep plain stores (their lines stay in the producing XCD's L2 for a same-XCD reader); A/B builds
-#endif
-template <int MODE>
-__device__ __forceinline__ void store_out16(void* p, u32x4_ v, bool wt) {
-  if (wt) store_out16<MODE>(p, v);
-  else *reinterpret_cast<u32x4_*>(p) = v;
-}
 template <int MODE>
 __device__ __forceinline__ void store_out8(void* p, unsigned a, unsigned b) {     // 8-byte form (attention outputs: row-per-lane fragments)
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
@@ -106,7 +98,6 @@ __device__ __forceinline__ void store_out8(void* p, unsigned a, unsigned b) {   
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
-  __device__ static inline void store(float* p, const float* o, bool) { store(p, o); }
   __device__ static inline void load(const float* p, float* o) {
     float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -138,13 +129,6 @@ template <> struct Vec<bf16> {
     for (int i = 0; i < 8; ++i) r[i] = (__bf16)o[i];          // 4 x v_cvt_pk_bf16_f32
     store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r));
   }
-  __device__ static inline void store(bf16* p, const float* o, bool wt) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
-    v8 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (__bf16)o[i];
-    store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r), wt);
-  }
 };
 
 template <> struct Vec<f16> {
@@ -160,12 +144,6 @@ template <> struct Vec<f16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (_Float16)o[i];          // 4 x v_cvt_pk_f16_f32
     store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r));
-  }
-  __device__ static inline void store(f16* p, const float* o, bool wt) {
-    v8 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (_Float16)o[i];
-    store_out16<DPB_OUT_STORE>(p, *reinterpret_cast<u32x4_*>(&r), wt);
   }
 };
 
@@ -219,7 +197,6 @@ template <> struct H16<0> {
   __device__ static inline f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   __device__ static inline void load8(const bf16* p, float* o) { Vec<bf16>::load(p, o); }
   __device__ static inline void store8(bf16* p, const float* o) { Vec<bf16>::store(p, o); }
-  __device__ static inline void store8(bf16* p, const float* o, bool wt) { Vec<bf16>::store(p, o, wt); }
   __device__ static inline bf16x8 pack8(const float* x) {
     bf16x8 r;
 #pragma unroll
@@ -243,7 +220,6 @@ template <> struct H16<1> {
   }
   __device__ static inline void load8(const bf16* p, float* o) { Vec<f16>::load(reinterpret_cast<const f16*>(p), o); }
   __device__ static inline void store8(bf16* p, const float* o) { Vec<f16>::store(reinterpret_cast<f16*>(p), o); }
-  __device__ static inline void store8(bf16* p, const float* o, bool wt) { Vec<f16>::store(reinterpret_cast<f16*>(p), o, wt); }
   __device__ static inline bf16x8 pack8(const float* x) {
     f16x8 r;
 #pragma unroll
@@ -251,6 +227,45 @@ template <> struct H16<1> {
     return *reinterpret_cast<bf16x8*>(&r);
   }
 };
+// Write-through stores WITHOUT the hand-placed pad: where the output tensor's base is wave-uniform (a kernel argument plus block-level offsets) the store can be
+// a buffer store with the sc1 cache bit through hipcc's own builtin -- the compiler then schedules it and pads its hazards itself (the asm form above always
+// pays `s_nop 1`: ~1 % of the iteration, profiles/r06_out_store_ab.txt).  Offsets are 32-bit BYTE offsets from the base: `ok` is false for tensors of 4 GiB or
+// more, which fall back to the asm form.  DPB_OUT_BUF=0 builds use the asm form everywhere (A/B).
+#ifndef DPB_OUT_BUF
+#define DPB_OUT_BUF 1
+#endif
+struct OutBuf {
+  __amdgpu_buffer_rsrc_t rs;
+  const char* base;
+  bool ok;
+};
+__device__ __forceinline__ OutBuf out_buf(void* base, long bytes) {
+  OutBuf b;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+  b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, -1, 0x00020000);     // raw buffer, 2^32 - 1 bytes: the caller's `ok` bounds it
+  b.base = (const char*)base;
+  b.ok = DPB_OUT_BUF != 0 && DPB_OUT_STORE == 1 && bytes > 0 && bytes < 4294967295L;
+  return b;
+}
+__device__ __forceinline__ void store_out16_at(const OutBuf& ob, void* p, u32x4_ v) {
+  if (ob.ok) __builtin_amdgcn_raw_buffer_store_b128(v, ob.rs, (unsigned)((const char*)p - ob.base), 0, 16 /* sc1 */);
+  else store_out16<DPB_OUT_STORE>(p, v);
+}
+template <int FL>
+__device__ __forceinline__ void store8_at(const OutBuf& ob, bf16* p, const float* o) {      // H16<FL>::store8 through the tensor's descriptor
+  const bf16x8 r = H16<FL>::pack8(o);
+  store_out16_at(ob, p, *reinterpret_cast<const u32x4_*>(&r));
+}
+template <typename T>
+__device__ __forceinline__ void vec_store_at(const OutBuf& ob, T* p, const float* o) {       // Vec<T>::store through the tensor's descriptor (fp32: plain)
+  if constexpr (std::is_same<T, float>::value) {
+    Vec<float>::store(p, o);
+  } else {
+    const bf16x8 r = H16<std::is_same<T, f16>::value ? 1 : 0>::pack8(o);      // the conversion Vec<T>::store does
+    store_out16_at(ob, p, *reinterpret_cast<const u32x4_*>(&r));
+  }
+}
+
 template <int FL> __device__ inline float ld16(const bf16* p) { return H16<FL>::up(p->v); }
 template <int FL> __device__ inline void st16(bf16* p, float v) { p->v = H16<FL>::dn(v); }
 

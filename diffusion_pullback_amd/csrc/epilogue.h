@@ -56,6 +56,7 @@ template <int FL, int WN, int SLD, int EPI>
 __device__ __forceinline__ void epilogue_ln(const GemmArgs& p, bf16* C, const bf16* R, const float* smem_f, int wave, int lane, int mrow0_block, const LnPre<WN>& q) {
   constexpr int NI = 2 * WN / 64;                                // chunks per lane: N / 8 chunks over 8 lanes
   static_assert(2 * WN % 64 == 0, "N = 2 WN must be a multiple of 64");
+  const OutBuf ob2 = out_buf(EPI == EPI_LN_TAN ? p.C2 : (void*)C, (long)p.M * p.ldc * 2);
   const int wy = wave >> 1, rg = lane >> 3, l = lane & 7;
   const float inv_c = 1.f / (float)p.N;
   float gam[NI][8];
@@ -120,7 +121,7 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& p, bf16* C, const bf
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += old[e];
       }
-      H16<FL>::store8((EPI == EPI_LN_TAN ? (bf16*)p.C2 : C) + (long)m * p.ldc + n, o);
+      store8_at<FL>(ob2, (EPI == EPI_LN_TAN ? (bf16*)p.C2 : C) + (long)m * p.ldc + n, o);
     }
   }
 }
@@ -134,6 +135,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
   constexpr int CPR = WN / 8;
   const int wx = wave & 1;
   const float* stage = smem_f + wave * 32 * SLD;
+  const OutBuf cb = out_buf(C, (long)p.M * p.ldc * 2);           // write-through stores through the output's buffer descriptor (common.h)
   if constexpr (EPI == EPI_GEGLU_FWD) {
     // forward pass (dpb_forward): y = a * gelu(g) straight from the FF-in product -- h [M][2F] is never written.  a and g are rounded to 16 bit first
     // and the expression is the primal GEGLU kernel's (elementwise.hip), so the result is bitwise what product + geglu_kernel give.
@@ -177,7 +179,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
         const float g1 = 0.5f * g8[e] * (1.f + er);
         o[e] = a8[e] * g1;
       }
-      H16<FL>::store8(C + (long)m * p.ldc + ncol, o);
+      store8_at<FL>(cb, C + (long)m * p.ldc + ncol, o);
     }
     (void)F2;
     return;
@@ -203,7 +205,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
         H16<FL>::load8(hp + 64, gp);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = p.alpha * (da[e] * ap[e] + dg[e] * gp[e]);      // ap = G1 = gelu(g), gp = G2 = a gelu'(g)
-        H16<FL>::store8(C + (long)m * p.ldc + (n0 >> 1) + c8 * 8, o);
+        store8_at<FL>(cb, C + (long)m * p.ldc + (n0 >> 1) + c8 * 8, o);
       }
     } else if constexpr (WN == 128) {                          // 256x256 tile: the wave's own 128 columns are a | g of 64 hidden units
       const int F2 = p.N;
@@ -223,7 +225,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
         H16<FL>::load8(hp + 64, gp);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = p.alpha * (da[e] * ap[e] + dg[e] * gp[e]);
-        H16<FL>::store8(C + (long)m * p.ldc + ((n0 + wx * WN) >> 1) + c8 * 8, o);
+        store8_at<FL>(cb, C + (long)m * p.ldc + ((n0 + wx * WN) >> 1) + c8 * 8, o);
       }
     }
     return;
@@ -281,12 +283,11 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { oa[e] += t1[e]; og[e] += t2[e]; }
       }
-      H16<FL>::store8(cp, oa);
-      H16<FL>::store8(cp + 64, og);
+      store8_at<FL>(cb, cp, oa);
+      store8_at<FL>(cb, cp + 64, og);
     }
     return;
   }
-  const bool wt = (long)p.M * p.N >= DPB_WT_MIN;
   if (p.vec_ok && n + 8 <= p.N) {
     // The operands of the epilogue (row bias, residual, the value accumulated so far) do not depend on the product: the loads of up to four items
     // are issued together, at clamped rows, before anything waits -- one memory round trip per batch instead of one per operand and item (the
@@ -335,7 +336,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t8[e];
         }
-        H16<FL>::store8(C + (long)m * p.ldc + n, v, wt);
+        store8_at<FL>(cb, C + (long)m * p.ldc + n, v);
       }
     }
   } else {

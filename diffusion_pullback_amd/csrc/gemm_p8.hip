@@ -396,6 +396,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
       // instead of four (K = 640 products spent a third of their time here).  Same additions in the same order as epilogue_slab: bitwise equal.
       const int c8 = lane & 7, r0 = lane >> 3, n = n0w + (wave & 1) * WN + c8 * 8;
       const bool act = n < p.N;                       // (the lane still STAGES its accumulators: other lanes read them)
+      const OutBuf cb8 = out_buf(C, (long)p.M * p.ldc * 2);          // write-through stores through the output's buffer descriptor (common.h)
       {
         float b8[8];
         if (p.bias && act) { Vec<float>::load(p.bias + n, b8); Vec<float>::load(p.bias + n + 4, b8 + 4); }
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += t8[e];
             }
-            H16<FL>::store8(C + (long)m * p.ldc + n, v);
+            store8_at<FL>(cb8, C + (long)m * p.ldc + n, v);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slab is re-staged by the next round: keep its reads ahead of those writes
           __builtin_amdgcn_wave_barrier();

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(320) void gemm_wres_kernel(GemmArgs p) {
   const unsigned stg_r = stg + ((lane >> 3) * SLD + (lane & 7) * 8) * 4;     // item u -> row 8 u + (lane >> 3), columns 8 (lane & 7) .. + 7
   const unsigned xs_r = lds0 + D * TILE + WAVES * STG + wave * XB + lane * 16;
   const float alpha = p.alpha;
+  const OutBuf cbw = out_buf(C, (long)M * ldc * 2);          // write-through stores through the output's buffer descriptor (common.h)
 
   int slot = 0;
   for (int it = 0; it < n_my; ++it) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(320) void gemm_wres_kernel(GemmArgs p) {
         for (int e = 0; e < 8; ++e) v[e] += t8[e];
       }
       const int m = m0 + 8 * u;
-      if (m < M) H16<FL>::store8(C + (unsigned long)((unsigned)m * (unsigned)ldc + (unsigned)(ncol0 + (lane & 7) * 8)), v);
+      if (m < M) store8_at<FL>(cbw, C + (unsigned long)((unsigned)m * (unsigned)ldc + (unsigned)(ncol0 + (lane & 7) * 8)), v);
     });
     if (++slot == D) slot = 0;
   }

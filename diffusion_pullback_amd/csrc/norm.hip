@@ -75,7 +75,7 @@ __device__ inline uint4 slab_chunk(const SlabSrc& s, long row, int c0) {
 template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
   constexpr int CH = TT<T>::CH;
-  const bool wt = (long)max(a.NT, a.Bp) * a.HW * a.C >= DPB_WT_MIN;   // write-through output stores (common.h)
+  const OutBuf yb = out_buf(a.y, (long)max(a.NT, a.Bp) * a.HW * a.C * (long)sizeof(T));   // write-through output stores (common.h)
   extern __shared__ float lch[];    // STATS, deterministic path: per-channel partial sums [rpi][C][2] (dynamic: rpi * C * 8 bytes)
   __shared__ float lsum[2 * 256];   // STATS, atomic path: [G][2]; apply pass, deterministic path: the reduced statistics [G][2]
   __shared__ double lseg[4][2 * 256];   // apply pass, deterministic path: 4 block-range segment sums per statistic
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) o[e] += old[e];
           }
-          Vec<T>::store(yp, o, wt);
+          vec_store_at<T>(yb, yp, o);
         }
       }
       if (STATS && a.det && cpg >= CH) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void gn_kernel(GNArgs a, int ppb) {
 template <typename T, int MODE, int MAXC>
 __global__ __launch_bounds__(512) void gn_fused_kernel(GNArgs a, int GC) {
   constexpr int CH = TT<T>::CH, NT = 512;
-  const bool wt = (long)max(a.NT, a.Bp) * a.HW * a.C >= DPB_WT_MIN;
+  const OutBuf yb = out_buf(a.y, (long)max(a.NT, a.Bp) * a.HW * a.C * (long)sizeof(T));
   __shared__ float red[4][NT];          // per-thread partials: [slot * 2 + stat][thread]
   __shared__ float seg[4 * 64 * 8];     // per (statistic, chunk column): 8 row-segment sums
   __shared__ double colsum[4][64];      // per chunk column of the window
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(GNArgs a, int GC) {
       {
         const uint4 pk = Raw<T>::pack(o);
         if constexpr (std::is_same<T, float>::value) *reinterpret_cast<uint4*>(yp) = pk;
-        else store_out16<DPB_OUT_STORE>(yp, u32x4_{pk.x, pk.y, pk.z, pk.w}, wt);
+        else store_out16_at(yb, yp, u32x4_{pk.x, pk.y, pk.z, pk.w});
       }
     }
   }
@@ -589,7 +589,7 @@ int launch_groupnorm(int dtype, int mode, const GNArgs& a, hipStream_t st) {
 template <typename T, int MODE, int MAXI>           // MAXI*64 >= chunks per row (C <= 1280 f32 / 2560 bf16 at MAXI = 5): sized per launch so
 __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {   // that the 320- / 640-channel rows do not carry 80 idle registers
   constexpr int CH = TT<T>::CH;
-  const bool wt = nrows * a.C >= DPB_WT_MIN;
+  const OutBuf yb = out_buf(a.y, nrows * a.C * (long)sizeof(T));
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {   // th
         float o[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) o[e] = x[i][e] * rstd * a.gamma[c * CH + e] + a.beta[c * CH + e];
-        Vec<T>::store(yp + c * CH, o, wt);
+        vec_store_at<T>(yb, yp + c * CH, o);
       }
     }
     return;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LNArgs a, long nrows) {   // th
 #pragma unroll
         for (int e = 0; e < CH; ++e) o[e] += old[e];
       }
-      Vec<T>::store(yp + c * CH, o, wt);
+      vec_store_at<T>(yb, yp + c * CH, o);
     }
   }
 }
@@ -694,7 +694,7 @@ __device__ inline float seg_sum(float v) {
 template <typename T, int MODE, int LPR, int NI>
 __global__ __launch_bounds__(256) void ln_rows_kernel(LNArgs a, long nrows) {
   constexpr int CH = TT<T>::CH, RPW = 64 / LPR;
-  const bool wt = nrows * a.C >= DPB_WT_MIN;
+  const OutBuf yb = out_buf(a.y, nrows * a.C * (long)sizeof(T));
   const int lane = threadIdx.x & 63, l = lane % LPR;
   const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool live = row < nrows;                 // whole row groups: every lane of a group agrees, the shuffles stay inside the group
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(LNArgs a, long nrows) {
       float o[CH];
 #pragma unroll
       for (int e = 0; e < CH; ++e) o[e] = x[i][e] * rstd * a.gamma[c * CH + e] + a.beta[c * CH + e];
-      Vec<T>::store(yp + c * CH, o, wt);
+      vec_store_at<T>(yb, yp + c * CH, o);
     }
     return;
   }
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(LNArgs a, long nrows) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) o[e] += old[e];
     }
-    Vec<T>::store(yp + c * CH, o, wt);
+    vec_store_at<T>(yb, yp + c * CH, o);
   }
 }
 
