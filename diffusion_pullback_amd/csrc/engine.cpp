@@ -132,7 +132,10 @@ void gemm_prep(dpb_engine* e, GemmArgs& a) {
 // dpb_debug_set("lazy_reduce", 0): every split-K product runs its own reduce kernel; the results are bitwise the same)
 int g_lazy_reduce = getenv("DPB_LAZY_REDUCE") ? atoi(getenv("DPB_LAZY_REDUCE")) : 1;
 // LayerNorm tangent / adjoint in the epilogue of the neighbouring 320-wide product (A/B switch: DPB_LN_FUSE=0, dpb_debug_set("ln_fuse", 0))
-int g_ln_fuse = getenv("DPB_LN_FUSE") ? atoi(getenv("DPB_LN_FUSE")) : 1;
+// Default OFF since round 6: with write-through output stores the separate product + ln_rows launches are 0.5 % ahead on the headline (118.4 / 118.5 vs 117.7 /
+// 117.9 it/s, same session, profiles/r06_switch_ab.txt) and equal on the 80-tangent pass -- the row-complete 128 x 320 tile is one block per CU, and what it saved was
+// mostly the dirty write-back of the intermediate at the kernel boundary.  The fused tile stays in the library (tests/test_gpu_edge.py) behind the switch.
+int g_ln_fuse = getenv("DPB_LN_FUSE") ? atoi(getenv("DPB_LN_FUSE")) : 0;
 int g_ln_kmax = getenv("DPB_LN_FUSE_KMAX") ? atoi(getenv("DPB_LN_FUSE_KMAX")) : 1024;   // adjoint: longest K that still takes the row-complete LayerNorm tile (tuning switch)
 
 int flush_pending(dpb_engine* e) {                 // the designated consumer did not come next: reduce the parked product the ordinary way

@@ -180,7 +180,7 @@ int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms
  * self-attention layers; 0 = the per-cotangent kernel of round 2; 6 = also route head dim 64 (SD-2.x) through the shared-probability adjoint kernels, measured
  * no faster there), "lazy_reduce" (1, default: a split-K product consumed by a one-launch GroupNorm or a
  * LayerNorm leaves its fp32 slabs to that kernel instead of running splitk_reduce_kernel; 0 = always reduce; bitwise the same results),
- * "ln_fuse" (LayerNorm in the epilogue of the 320-wide products), "cross_primal" (1, default: the forward of a text-conditioned attention layer is
+ * "ln_fuse" (0, default since round 6: separate launches; 1 = LayerNorm in the epilogue of the 320-wide products), "cross_primal" (1, default: the forward of a text-conditioned attention layer is
  * ONE launch; 0 = GEMM + softmax + transpose + GEMM), "geglu_fwd" (1, default: dpb_forward applies GEGLU in the epilogue of the unsplit FF-in products), "iter_alias" (1, default: inside dpb_pullback_iterate the tap's
  * tangent passes from the tangent to the adjoint pass on the device, U is written by the last iteration only; 0 = fp32 round trip through U every iteration; bitwise equal).
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces

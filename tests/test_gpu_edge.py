@@ -317,7 +317,7 @@ def test_layernorm_fused_into_product_epilogue_matches_separate_kernels(dtype):
             # cross-attention q), the one behind the FF-in adjoint (K = 8 C) stays a separate kernel
             assert launches[1][0] == launches[0][0] - 3 and launches[1][1] == launches[0][1] - 2, launches
     finally:
-        L.check(lib.dpb_debug_set(b"ln_fuse", 1))
+        L.check(lib.dpb_debug_set(b"ln_fuse", 0))      # the default since round 6
 
 
 def test_forward_pass_shortcuts_match_the_unfused_kernels():
