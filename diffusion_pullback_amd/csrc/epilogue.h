@@ -15,6 +15,13 @@
 #pragma once
 #include "kernels.h"
 
+#ifndef DPB_SLAB_FULL_LINES
+#define DPB_SLAB_FULL_LINES 1   // split-K slabs stored one 16-byte chunk per lane, whole lines per instruction (0: the 8-floats-per-lane form of rounds 1-5; A/B builds)
+#endif
+#ifndef DPB_SLAB_STORE
+#define DPB_SLAB_STORE 0        // store flavour of the fp32 slabs (common.h store_out16): 0 plain, 1 sc1, 2 nt (A/B builds)
+#endif
+
 namespace dpb {
 
 // Row-complete tiles (the block holds whole rows of the product: BN = N, two waves side by side).  64 rows of fp32 accumulators are staged as
@@ -235,6 +242,28 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, bf16* C, const 
   static_assert(64 % CPR == 0, "a lane keeps its column across items");
   const int c8 = lane % CPR, r0 = lane / CPR;
   const int n = n0 + wx * WN + c8 * 8;
+  if (DPB_SLAB_FULL_LINES && EPI == EPI_PLAIN && p.splitk > 1 && !(p.N & 3)) {   // split-K partial, N a multiple of 4 (else the 8-floats-per-lane form below)
+    // One 16-byte chunk per lane and instruction, consecutive lanes on consecutive chunks of a row: every store instruction writes whole 128-byte lines
+    // (the 8-floats-per-lane form wrote the two halves of each 32 bytes in two instructions: half lines, which a write-through store turns into a
+    // read-modify-write at the memory side).  Same values at the same addresses.
+    constexpr int CPR4 = WN / 4;
+    if constexpr (64 % CPR4 == 0) {
+      constexpr int RPI4 = 64 / CPR4;
+      const int c4 = lane % CPR4, r4 = lane / CPR4, n4 = n0 + wx * WN + c4 * 4;
+      {
+#pragma unroll
+        for (int it = 0; it < 32 / RPI4; ++it) {
+          const int row = it * RPI4 + r4, m = mrow0 + row;
+          if (m >= p.M || n4 >= p.N) continue;
+          float v[4];
+          Vec<float>::load(stage + row * SLD + c4 * 4, v);
+          const u32x4_ bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          store_out16<DPB_SLAB_STORE>(p.slab + slab_idx * (long)p.M * p.N + (long)m * p.N + n4, bits);
+        }
+        return;
+      }
+    }
+  }
   if (n >= p.N) return;
   if (EPI == EPI_PLAIN && p.splitk > 1) {         // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel (or by the consumer: SlabSrc)
 #pragma unroll
