@@ -429,5 +429,12 @@ def test_p8_isa_keeps_fragment_registers_untouched_until_their_wait(tmp_path):
         vm = [int(m) for w in waits for m in re.findall(r"vmcnt\((\d+)\)", w)]
         assert vm.count(10) >= 2 and vm.count(6) >= 3, (name, sorted(set(vm)))   # two unrolled K tiles + the prologue (drains: prologue / epilogue only)
     assert n_reads >= 8 * 2 * 24
+    # output stores (round 6, common.h): write-through.  The epilogue's 16-byte 16-bit stores are hipcc-scheduled buffer stores with the sc1 bit (through the
+    # output tensor's descriptor); the asm fallback (tensors of 4 GiB or more) must carry its pad INSIDE the asm block -- hipcc pads nothing behind an asm
+    # statement, and a VALU write of the data registers right behind a > 64-bit store corrupts it
+    assert len(re.findall(r"buffer_store_dwordx4 .* sc1", text)) >= len(kernels) // 2
+    asm_blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, flags=re.S)
+    stores = [b for b in asm_blocks if "global_store_dwordx4" in b]
+    assert stores and all(re.search(r"global_store_dwordx4 [^\n]* sc1\s*\n\s*s_nop 1", b) for b in stores), "an asm write-through store without its s_nop 1"
     for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", text):
         assert m.group(1) == "0"
