@@ -704,7 +704,7 @@ GemmPlan gemm_plan(int dtype, const GemmArgs& a) {
       pl.kind = PLAN_RING; pl.tile = 520; s = 1;
     } else if (const int dt = gemm_uses_dma(dtype, a)) {
       pl.kind = PLAN_RING; pl.tile = dt;
-      s = a.epi != EPI_PLAIN ? 1 : gemm_pick_splitk_dma(a, dt);
+      s = (a.epi != EPI_PLAIN || dt == 540) ? 1 : gemm_pick_splitk_dma(a, dt);      // (the weights-resident kernel never splits K, whatever a debug override asks)
     } else {
       pl.kind = gemm_uses_big_tile(dtype, a) ? PLAN_REG128 : PLAN_REG64;
       pl.tile = pl.kind == PLAN_REG128 ? 128 : 64;

@@ -241,6 +241,12 @@ def test_gemm_dispatch_plans_respect_the_slab_scratch_and_the_tile_contracts():
     assert plan(L.DPB_BF16, 81920, 320, 320) == (2, 540, 1) and plan(L.DPB_F16, 327680, 960, 320) == (2, 540, 1)
     assert plan(L.DPB_BF16, 20480, 320, 320)[1] != 540 and plan(L.DPB_BF16, 81920, 960, 320)[1] != 540
     assert plan(L.DPB_BF16, 81920, 640, 640)[1] != 540 and plan(L.DPB_BF16, 327680, 2560, 320, epi=1)[1] != 540
+    try:                                                                   # a forced split count never reaches it (it has no slab path), a forced tile only where it applies
+        L.check(lib.dpb_debug_set(b"gemm_splitk", 4)); L.check(lib.dpb_debug_set(b"gemm_tile", 540))
+        assert plan(L.DPB_BF16, 20480, 320, 320) == (2, 540, 1)
+        assert plan(L.DPB_BF16, 20480, 640, 640)[1] == 515
+    finally:
+        L.check(lib.dpb_debug_set(b"gemm_splitk", 0)); L.check(lib.dpb_debug_set(b"gemm_tile", 0))
     # the launch that overflowed: now the 256x256 tile, unsplit; and the same product forced onto the 128x128 ring keeps within the scratch
     assert plan(L.DPB_BF16, 10240, 1280, 5120) == (2, 530, 1)
     assert plan(L.DPB_BF16, 20480, 320, 2880, 64, 320)[0] == 3            # N = 320 (37.5 % padding on 256-column tiles): the halo-tile kernel keeps the 64x64-level convolutions
