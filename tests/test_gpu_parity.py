@@ -410,6 +410,37 @@ def test_p8_dispatch_is_bitwise_the_ring_dispatch_on_a_network(dtype):
         assert torch.equal(a, b), f"{name}: max |d| = {(a - b).abs().max().item():.3e}"
 
 
+def test_wres_dispatch_is_bitwise_the_ring_dispatch_on_a_network():
+    """Inside a network (two-level SD-shaped U-Net, 64 x 64 latents) at 12 tangents -- 49152 rows at the 64 x 64 level, the row count from which the
+    dispatch hands the K = 320 linear layers (proj_in, attention out-proj, cross-attention q / out, proj_out; tangent and adjoint passes, with their residual /
+    accumulate operands) to the weights-resident streaming kernel.  With dpb_debug_set("wres", 0) they run on the rings / the 8-phase tile as in round 5:
+    same MFMA order, same epilogue arithmetic -- tangents and cotangents must be bitwise equal."""
+    from diffusion_pullback_amd import PullbackUNet, lib as L
+    from oracle import unet_sd
+    lib = L.load()
+    cfg = unet_sd.SDConfig(block_out_channels=(320, 640), layers_per_block=1, down_attn=(True, True), up_attn=(True, True),
+                           heads=(8, 8), cross_dim=768, sample_size=64, ctx_len=77)
+    p = unet_sd.init_params(cfg, seed=1)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 4, 64, 64, generator=g); ctx = torch.randn(1, 77, 768, generator=g)
+    V = torch.randn(12, 4 * 64 * 64, generator=g).cuda(); U = torch.randn(12, 640 * 32 * 32, generator=g).cuda()
+    tap = ("mid", 0)
+    net = PullbackUNet("sd", cfg, p, dtype=torch.bfloat16, device=_dev(), max_batch=1, max_rank=12, upto=tap, verbose=False)
+    out = {}
+    try:
+        for on in (1, 0):
+            L.check(lib.dpb_debug_set(b"wres", on))
+            net.engine.primal(z, 696.2727, ctx, tap)
+            net.engine.profile(True)
+            out[on] = (net.engine.jvp(tap, V).clone(), net.engine.vjp(tap, U).clone(), net.engine.profile_read(12)[0])
+            net.engine.profile(False)
+    finally:
+        L.check(lib.dpb_debug_set(b"wres", 1))
+    assert out[1][2] >= 6 and out[0][2] == 0, (out[1][2], out[0][2])          # the weights-resident kernel really ran (and did not with the switch off)
+    for a, b, name in zip(out[1][:2], out[0][:2], ("jvp", "vjp")):
+        assert torch.isfinite(a).all() and torch.equal(a, b), f"{name}: max |d| = {(a - b).abs().max().item():.3e}"
+
+
 def test_batched_samples_match_single_sample_runs():
     """Several x_t samples advanced together (shared weight stream) give the same bases as one-at-a-time runs."""
     from diffusion_pullback_amd import PullbackUNet
