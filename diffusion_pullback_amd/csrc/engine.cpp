@@ -966,7 +966,7 @@ int dpb_engine_create(const dpb_net_desc* net, dpb_engine** out) {
   const size_t nio = (size_t)std::max(e->maxB, e->maxT) * maxrc * sizeof(float);
   e->io_in = take(nio);
   e->io_out = take(nio);
-  e->orth_stride = align_up(orth_scratch_bytes(56, (long)e->bufs[e->x_buf].rows * e->x_channels));
+  e->orth_stride = align_up(orth_scratch_bytes(std::min(ORTH_MAX_RANK, std::max(56, e->maxT)), (long)e->bufs[e->x_buf].rows * e->x_channels));   // k <= max_tangents
   e->orth = take(e->orth_stride * (size_t)e->maxB);
   e->slab = take(e->slab_bytes);
   e->zeros = take(256);
@@ -1152,7 +1152,7 @@ int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv
 int dpb_orth_checked(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, size_t scratch_bytes, int k, int64_t N,
                      void* stream) {
   if (!W || !Vprev || !V || !s || !conv || !scratch) return fail("null argument");
-  if (k < 1 || k > 56 || N < 1) return fail("dpb_orth: k=%d outside [1,56] or N=%lld < 1", k, (long long)N);
+  if (k < 1 || k > ORTH_MAX_RANK || N < 1) return fail("dpb_orth: k=%d outside [1,%d] or N=%lld < 1", k, ORTH_MAX_RANK, (long long)N);
   const size_t need = orth_scratch_bytes(k, N);
   if (scratch_bytes < need) return fail("dpb_orth: scratch of %zu bytes, dpb_orth_scratch_bytes(%d, %lld) = %zu", scratch_bytes, k, (long long)N, need);
   OrthArgs a;
@@ -1161,14 +1161,15 @@ int dpb_orth_checked(const float* W, const float* Vprev, float* V, float* s, flo
   return launch_orth(a, (hipStream_t)stream);
 }
 
-size_t dpb_orth_scratch_bytes(int k, int64_t N) { return (k < 1 || k > 56 || N < 1) ? 0 : orth_scratch_bytes(k, N); }
+size_t dpb_orth_scratch_bytes(int k, int64_t N) { return (k < 1 || k > ORTH_MAX_RANK || N < 1) ? 0 : orth_scratch_bytes(k, N); }
 
 static int g_iter_alias = getenv("DPB_ITER_ALIAS") ? atoi(getenv("DPB_ITER_ALIAS")) : 1;   // A/B switch: 0 = convert U out and back in every iteration
+static int g_orth_batch = getenv("DPB_ORTH_BATCH") ? atoi(getenv("DPB_ORTH_BATCH")) : 1;   // A/B switch: 0 = re-orthonormalise the samples of a batch one by one
 static int g_graph_iterate = 0;      // dpb_debug_set("graph_iterate", 1): replay the power iteration as a captured hipGraph (measurement option)
 
 int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, float* conv, int k, int n_iters) {
   if (!e || !V || !U || !s || !conv) return fail("null argument");
-  if (k < 1 || k > 56) return fail("pca_rank k=%d outside [1,56]", k);
+  if (k < 1 || k > ORTH_MAX_RANK) return fail("pca_rank k=%d outside [1,%d]", k, ORTH_MAX_RANK);
   const int B = e->cur_batch;                       // samples advanced together: one weight stream for all of them
   if (int r = check_tap(e, tap, k * (B > 0 ? B : 1))) return r;
   const int nt = k * B;
@@ -1184,10 +1185,22 @@ int dpb_pullback_iterate(dpb_engine* e, int tap, float* V, float* U, float* s, f
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
     if (int r = vjp_pass(e, tap, keep ? nullptr : U, nt, Wm)) return r;
     launches += e->n_launch; fl += e->flops; gb += e->gbytes;
-    for (int b = 0; b < B; ++b)                     // independent k x N re-orthonormalisation per sample
-      if (int r = dpb_orth(Wm + (long)b * k * N, V + (long)b * k * N, V + (long)b * k * N, s + b * k, conv + 2 * b,   // in place: see dpb.h
-                           e->ws + e->orth + (size_t)b * e->orth_stride, k, N, e->stream)) return r;
-    launches += 4 * B;
+    {                                               // independent k x N re-orthonormalisation per sample, all samples in one set of four launches
+      OrthArgs a;                                   // (in place, V is Vprev: see dpb.h)
+      a.W = Wm; a.Vprev = V; a.V = V; a.s = s; a.conv = conv; a.scratch = (double*)(e->ws + e->orth); a.k = k; a.N = N;
+      a.scratch_bytes = orth_scratch_bytes(k, N);
+      a.batch = B; a.stride_w = (long)k * N; a.stride_v = (long)k * N; a.stride_s = k; a.stride_conv = 2; a.scratch_stride = e->orth_stride;
+      if (g_orth_batch) {
+        if (int r = launch_orth(a, e->stream)) return r;
+      } else {                                      // A/B switch DPB_ORTH_BATCH=0: four launches per sample, as rounds 1-5 (same bits)
+        a.batch = 1;
+        for (int b = 0; b < B; ++b) {
+          if (int r = launch_orth(a, e->stream)) return r;
+          a.W += a.stride_w; a.Vprev += a.stride_v; a.V += a.stride_v; a.s += k; a.conv += 2; a.scratch += e->orth_stride / sizeof(double);
+        }
+      }
+    }
+    launches += g_orth_batch ? 4 : 4 * B;
     return 0;
   };
   int it = 0;

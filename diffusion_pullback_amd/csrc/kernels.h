@@ -198,7 +198,11 @@ struct OrthArgs {
   double* scratch = nullptr;     // >= orth_scratch_bytes(k, N)
   size_t scratch_bytes = 0;
   int k = 0; long N = 0;
+  // samples of a batch in ONE set of launches (dpb_pullback_iterate): sample b at W + b*stride_w, Vprev / V + b*stride_v, s + b*stride_s,
+  // conv + b*stride_conv (elements), scratch + b*scratch_stride (bytes, a multiple of 8, >= orth_scratch_bytes)
+  int batch = 1; long stride_w = 0, stride_v = 0, stride_s = 0, stride_conv = 0; size_t scratch_stride = 0;
 };
+constexpr int ORTH_MAX_RANK = 128;   // largest pca_rank of the re-orthonormalisation (orth.hip: the k x k fp64 matrix of the eigen-solve lives in LDS)
 int launch_orth(const OrthArgs& a, hipStream_t st);
 size_t orth_scratch_bytes(int k, long N);
 

@@ -18,7 +18,8 @@ Deliberate differences:
   * V0 is drawn on the CPU generator (reproducible; the reference's device RNG draw is not) or injected;
   * each singular vector is signed for non-negative overlap with the previous iterate (LAPACK's
     sign is arbitrary), which only makes the reference's stop rule well defined;
-  * pca_rank <= 56 (the reference's signature default is 50, its call sites use 2..10: main.py:33, BASELINE configs).
+  * pca_rank <= 128 (RANK_LIMIT: the k x k eigen-solve of the re-orthonormalisation lives in LDS; the reference's signature default is 50, its
+    call sites use 2..10: main.py:33, BASELINE configs); an engine is built for `max_rank` tangents (default 56).
 """
 from __future__ import annotations
 
@@ -32,7 +33,8 @@ from . import lib as L
 from .engine import Engine
 from .tape import build_ddpm, build_sd
 
-MAX_RANK = 56
+MAX_RANK = 56          # default tangent capacity of an engine (workspace sizing)
+RANK_LIMIT = 128       # largest pca_rank of the library (csrc/kernels.h ORTH_MAX_RANK)
 
 
 class UNetOutput:
@@ -96,8 +98,9 @@ class PullbackUNet:
     def _pullback(self, x, t, ctx, op, block_idx, k, chunks, min_iter, max_iter, thr, V0):
         if x.shape[0] != 1:
             raise ValueError("local_encoder_pullback expects a single sample (batch 1), as the reference does")
-        if not (1 <= k <= self.max_rank):
-            raise ValueError(f"pca_rank={k} outside [1, {self.max_rank}] supported by the HIP engine")
+        if not (1 <= k <= min(self.max_rank, RANK_LIMIT)):
+            raise ValueError(f"pca_rank={k} outside [1, {min(self.max_rank, RANK_LIMIT)}] supported by the HIP engine (built for max_rank={self.max_rank} "
+                             f"tangents; the library's limit is {RANK_LIMIT})")
         key = self._tap(op, block_idx)
         eng = self.engine
         n_in = eng.n_in

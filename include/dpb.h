@@ -117,14 +117,14 @@ int dpb_jvp(dpb_engine* e, int tap_buf, const float* V, int nt, float* U);
 /* W = J^T U : adjoint pass wrt the input only.  Replaces: autograd.functional.jacobian, utils.py:790-797. */
 int dpb_vjp(dpb_engine* e, int tap_buf, const float* U, int nt, float* W);
 
-/* Thin SVD of W [k][N] (fp32, k <= 56): V rows = right singular vectors (descending), s = sqrt(singular values),
+/* Thin SVD of W [k][N] (fp32, k <= 128): V rows = right singular vectors (descending), s = sqrt(singular values),
  * conv[0] = ||V - Vprev||_2, conv[1] = max(|V - Vprev| - 1e-5|V|).  scratch: device memory of >= dpb_orth_scratch_bytes(k, N) bytes (Gram
  * matrix and distance partials per block, added in block order: the result is bitwise reproducible).  V may alias Vprev (in place:
  * every element of Vprev is read by the thread that overwrites it, after the Gram pass has finished with it).
  * Replaces: torch.linalg.svd + dist/allclose inputs, utils.py:799-806.  Engine-independent. */
 int dpb_orth(const float* W, const float* Vprev, float* V, float* s, float* conv, void* scratch, int k, int64_t N,
              void* hip_stream);
-size_t dpb_orth_scratch_bytes(int k, int64_t N);   /* 0 for k outside [1, 56] */
+size_t dpb_orth_scratch_bytes(int k, int64_t N);   /* 0 for k outside [1, 128] */
 /* The same with the caller's scratch size stated and validated.  CONTRACT CHANGE of round 3, called out here because dpb_orth cannot check it: the
  * scratch grew from 8 (3 k^2 + 2) bytes to dpb_orth_scratch_bytes(k, N) (per-block partials of the fixed-order reductions, up to ~129 k^2 + 512
  * doubles); a caller that still sizes it by the old rule gets out-of-bounds device writes from dpb_orth.  New callers bind THIS entry point
@@ -135,7 +135,7 @@ int dpb_orth_checked(const float* W, const float* Vprev, float* V, float* s, flo
 /* n_iters full power iterations with no host synchronisation: V <- orth(J^T J V), U = J V_prev, for all B samples
  * of the last dpb_primal together (independent bases, one shared weight stream; B*k <= max_tangents).
  * V [B][k][N_in] in/out, U [B][k][N_h] out, s [B][k] out, conv [B][2] out (of the last iteration).
- * Replaces: the loop body utils.py:756-808 (k <= 56), once per sample of the batch. */
+ * Replaces: the loop body utils.py:756-808 (k <= 128), once per sample of the batch. */
 int dpb_pullback_iterate(dpb_engine* e, int tap_buf, float* V, float* U, float* s, float* conv, int k, int n_iters);
 
 /* DDIM update (utils.py:301-306 / :1220-1225, eta = 0) and the x-space-guidance axpy (edit.py:490, :501). */
@@ -186,7 +186,8 @@ int dpb_engine_profile_overhead(const dpb_engine* e, double* bracket_overhead_ms
  * Environment, read once per process (tuning / ablation only): DPB_GEMM_OVERRIDE="MxNxK:gather=code/split,..." forces
  * kernel and split count per product shape; DPB_P8 (0: no 8-phase tile), DPB_WRES (0: no weights-resident kernel), DPB_WRES_MIN_M, DPB_TILE256, DPB_CONV_HALO, DPB_SPLITK_TARGET, DPB_GEMM_ORDER, DPB_GN_FUSED, DPB_GN_BLOCKS,
  * DPB_GN_DETERMINISTIC, DPB_LN_ROWS, DPB_LN_FUSE, DPB_LAZY_REDUCE, DPB_ATTN_WAVES, DPB_ATTN_MULTI, DPB_ATTN_SHARED, DPB_ATTN_XCD, DPB_FUSED_ATTN_MIN_L,
- * DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN, DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants; DPB_GEMM_TRACE=1 prints every
+ * DPB_NO_FUSED_ATTN, DPB_NO_CROSS_ATTN, DPB_NO_GEGLU_FUSE switch individual kernels / fusions off or pick their variants; DPB_EIG_PAR (0: the one-wave cyclic
+ * eigen-solve of rounds 1-5 for every k <= 56, 2: the round-robin one for every k), DPB_ORTH_BATCH (0: the samples of a batch re-orthonormalised one by one); DPB_GEMM_TRACE=1 prints every
  * product and synchronises after it (debugging). */
 int dpb_debug_set(const char* key, int value);
 

@@ -38,6 +38,31 @@ def test_rank_one_and_max_rank_match_full_jacobian_svd(toy):
         assert torch.allclose((vT @ vT.T).cpu(), torch.eye(k), atol=1e-3)
 
 
+def test_ranks_above_56_match_full_jacobian_svd(toy):
+    """pca_rank 57..128 (round 6: round-robin Jacobi eigen-solve on sixteen waves, row-tiled apply kernel): the reference takes any
+    pca_rank (utils.py:722, default 50); 96 is the largest rank whose eigenvector matrix lives in LDS, 128 the library's limit."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    f, cfg, p, _ = toy
+    net = PullbackUNet("sd", cfg, p, dtype=torch.float32, device=DEV, max_batch=1, max_rank=128, verbose=False)
+    J = torch.autograd.functional.jacobian(
+        lambda a: unet_sd.forward(p, cfg, a, f["t"], f["ctx"], stop=("mid", 0)).reshape(-1), f["z"]).reshape(-1, 256)
+    sv = torch.linalg.svdvals(J)
+    _, _, Vh = torch.linalg.svd(J, full_matrices=False)
+    for k in (57, 96, 128):
+        V0 = torch.linalg.qr(torch.randn(256, k, generator=torch.Generator().manual_seed(k)))[0].T.contiguous()
+        u, s, vT = net.local_encoder_pullback_zt(f["z"], f["t"], f["ctx"], op="mid", block_idx=0, pca_rank=k, chunk_size=25,
+                                                 min_iter=10, max_iter=60, convergence_threshold=1e-5, V0=V0)
+        assert u.shape == (J.shape[0], k) and s.shape == (k,) and vT.shape == (k, 256)
+        assert torch.allclose(s.cpu()[:20], sv[:20], rtol=5e-3), (k, s.cpu()[:20], sv[:20])
+        assert (abs_cos(vT[:8], Vh[:8]) > 0.99).all()
+        assert torch.allclose((vT @ vT.T).cpu(), torch.eye(k), atol=1e-3)
+        assert (s[:-1] >= s[1:]).all()              # descending
+    with pytest.raises(ValueError):                 # the library's limit, not the engine's capacity
+        PullbackUNet("sd", cfg, p, dtype=torch.float32, device=DEV, max_batch=1, max_rank=200, verbose=False).local_encoder_pullback_zt(
+            f["z"], f["t"], f["ctx"], op="mid", block_idx=0, pca_rank=129)
+
+
 def test_error_behaviour(toy):
     f, cfg, p, net = toy
     from diffusion_pullback_amd import DpbError

@@ -116,9 +116,13 @@ def test_orth_matches_svd():
     from diffusion_pullback_amd import lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(4)
-    for k, n in [(1, 64), (3, 1000), (5, 16384), (10, 196608), (16, 4099), (17, 3000), (50, 16384)]:
-        scale = torch.logspace(0, -2, k)[:, None]
-        W = (torch.randn(k, k, generator=g) @ (scale * torch.linalg.qr(torch.randn(n, k, generator=g))[0].T)).float()
+    for k, n in [(1, 64), (3, 1000), (5, 16384), (10, 196608), (16, 4099), (17, 3000), (31, 700), (50, 16384), (56, 2000), (57, 2000), (64, 16384),
+                 (95, 3001), (96, 16384), (97, 1000), (128, 16384), (128, 200)]:      # 17..128: the round-robin eigen-solve; 57..: the row-tiled apply kernel
+        scale = torch.logspace(0, -2, k)[:, None]          # (singular values of W over two decades: eigenvalues of the Gram matrix over four)
+        mix = torch.randn(k, k, generator=g)
+        if k > 56:                                         # orthogonal mixing: the singular values stay `scale` (a Gaussian k x k factor at k = 128 adds
+            mix = torch.linalg.qr(mix)[0]                  # 3-4 decades of its own, beyond what a Gram-matrix method resolves to the 1e-5 bar below)
+        W = (mix @ (scale * torch.linalg.qr(torch.randn(n, k, generator=g))[0].T)).float()
         Vp = torch.linalg.qr(torch.randn(n, k, generator=g))[0].T.contiguous().float()
         _, s_ref, V_ref = torch.linalg.svd(W.double(), full_matrices=False)
         Wd, Vpd = W.cuda(), Vp.cuda()

@@ -363,8 +363,9 @@ def test_orth_scratch_contract_follows_the_block_layout():
     assert f(5, 4 * 64 * 64) == 8 * (25 * (1 + 2 * 64) + 2 * 64)            # 64 slices of 256 columns: the SD latent
     assert f(5, 3 * 256 * 256) == 8 * (25 * (1 + 2 * 64) + 2 * 256)         # both block counts capped: the DDPM-256 image
     assert f(3, 100) == 8 * (9 * (1 + 2 * 1) + 2 * 1)                       # one ragged slice
-    assert f(56, 4 * 64 * 64) == 8 * (56 * 56 * (1 + 2 * 64) + 2 * 64)      # the largest supported rank
-    assert f(57, 4 * 64 * 64) == 0 and f(0, 4 * 64 * 64) == 0 and f(5, 0) == 0
+    assert f(56, 4 * 64 * 64) == 8 * (56 * 56 * (1 + 2 * 64) + 2 * 64)      # the largest rank of rounds 1-5
+    assert f(128, 4 * 64 * 64) == 8 * (128 * 128 * (1 + 2 * 64) + 2 * 64)   # the library's limit since round 6 (same layout: the eigen-solve reuses partial 0's slots)
+    assert f(129, 4 * 64 * 64) == 0 and f(0, 4 * 64 * 64) == 0 and f(5, 0) == 0
     assert all(f(k, n) <= f(k, 2 * n) for k in (1, 5, 50) for n in (64, 1000, 16384, 100000))
 
 
