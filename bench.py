@@ -28,6 +28,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes fails with hipIpcGetMemHandle errors without it (set before HIP loads)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
