@@ -61,28 +61,30 @@ class Tape:
         if key in self._wcache:
             return self._wcache[key]
         names = name if isinstance(name, tuple) else (name,)
-        w = torch.cat([self.p[n + ".weight"].float() for n in names], dim=0)
+        dev = self.device                 # pad / permute / convert on the engine's device (the fp32 tensors are uploaded once; on the CPU this was 5 s of an SD build)
+        w = torch.cat([self.p[n + ".weight"].detach().to(device=dev, dtype=torch.float32) for n in names], dim=0)
         perm = None
         if interleave:
             f = w.shape[0] // 2
-            blk = torch.arange(f).reshape(f // interleave, interleave)
+            blk = torch.arange(f, device=dev).reshape(f // interleave, interleave)
             perm = torch.stack([blk, blk + f], dim=1).reshape(-1)              # a-block b, g-block b, a-block b+1, ...
             w = w[perm]
         if w.dim() == 2:
             w = w[:, :, None, None]
         cout, cin, kh, kw = w.shape
-        wf = torch.zeros(cout, kh, kw, cin_p)
+        wf = torch.zeros(cout, kh, kw, cin_p, device=dev)
         wf[..., :cin] = w.permute(0, 2, 3, 1)
         pf = self._dev(wf.reshape(cout, kh * kw * cin_p), self.dtype)
         pa = 0
         if need_adj:
-            wa = torch.zeros(cin_p, kh, kw, cout_p)
+            wa = torch.zeros(cin_p, kh, kw, cout_p, device=dev)
             wa[:cin, :, :, :cout] = w.permute(1, 2, 3, 0)
             pa = self._dev(wa.reshape(cin_p, kh * kw * cout_p), self.dtype)
         bs = [self.p.get(n + ".bias") for n in names]
         b = None
         if any(x is not None for x in bs):
-            b = torch.cat([x.float() if x is not None else torch.zeros(self.p[n + ".weight"].shape[0]) for x, n in zip(bs, names)])
+            b = torch.cat([x.detach().to(device=dev, dtype=torch.float32) if x is not None else torch.zeros(self.p[n + ".weight"].shape[0], device=dev)
+                           for x, n in zip(bs, names)])
             if perm is not None:
                 b = b[perm]
         pb = self._dev(b.float(), torch.float32) if b is not None else 0
