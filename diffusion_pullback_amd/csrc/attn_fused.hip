@@ -202,7 +202,16 @@ __global__ __launch_bounds__((FA<D, W>::NT)) void attn_fwd_kernel(FusedArgs a, b
   const bf16* Vp = a.V + b * LC + h * D;
   bf16x8 qf[F::NS];
   load_outer_frags<D>(a.Q + b * LC + (long)q * a.C + h * D, qf, lhi);
-  const float c2 = a.scale * 1.44269504088896f;          // scores in log2 units
+  const float c2 = a.scale * 1.44269504088896f;          // scores in log2 units (c2 > 0: the max commutes with the scaling)
+  // Round 6 (the DDIM / guidance loop's kernel: 19 % of a batch-20 forward).  The loop was VALU-bound 2-3x over its MFMAs (per 128 keys: 28 MFMAs = 896
+  // cycles against 250 VALU + 78 packed + 68 exp): (i) the running max is taken over the RAW scores and scaled once; (ii) DEFERRED rescale: the accumulators
+  // keep a stale max until some query of the wave has outgrown it by more than 2^FWD_THR (wave-uniform branch; P = exp2(s - m_stale) <= 2^FWD_THR, exact in
+  // exact arithmetic because l carries the same factor) -- after the first tiles the 32 multiplies per 32 keys are not executed at all; (iii) d = 40: the row
+  // sum l comes out of the P V product itself (a ones column in V's first padding column, as attn_jvp_kernel's delta), not from 16 adds per 32 keys.
+  // The emitted statistics are (m_stale, 1 / l): any consistent pair reproduces P = exp(s - m) / l in the tangent / adjoint kernels.
+  constexpr float FWD_THR = 4.f;
+  constexpr bool LSUM = F::DP > D;
+  constexpr unsigned ONE16 = FL ? 0x3C00u : 0x3F80u, VONE = LSUM ? ONE16 : 0u;
   f32x16 acc[F::ND];
 #pragma unroll
   for (int d = 0; d < F::ND; ++d)
@@ -210,14 +219,14 @@ __global__ __launch_bounds__((FA<D, W>::NT)) void attn_fwd_kernel(FusedArgs a, b
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   RowRegs<D, F::NT> rK, rV;
-  fetch_row<D, F::NT>(Kp, a.C, rK, tid); fetch_row<D, F::NT>(Vp, a.C, rV, tid);
+  fetch_row<D, F::NT>(Kp, a.C, rK, tid); fetch_row<D, F::NT, VONE>(Vp, a.C, rV, tid);
   for (int k0 = 0; k0 < a.L; k0 += F::BI) {
     __syncthreads();
     commit_row<D, F::NT>(rK, sK, tid); commit_row<D, F::NT>(rV, sV, tid);
     __syncthreads();
     if (k0 + F::BI < a.L) {
       const int k1 = k0 + F::BI;
-      fetch_row<D, F::NT>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, F::NT>(Vp + (long)k1 * a.C, a.C, rV, tid);
+      fetch_row<D, F::NT>(Kp + (long)k1 * a.C, a.C, rK, tid); fetch_row<D, F::NT, VONE>(Vp + (long)k1 * a.C, a.C, rV, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < F::BI / 32; ++kb) {
@@ -226,22 +235,30 @@ __global__ __launch_bounds__((FA<D, W>::NT)) void attn_fwd_kernel(FusedArgs a, b
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int stp = 0; stp < F::NS; ++stp) s = MFMA(lds_a_frag(sK, kb * 32 + l31, F::LDR, stp * 16 + lhi * 8), qf[stp], s);
-      float mx = -INFINITY;
+      float mx = s[0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] *= c2; mx = fmaxf(mx, s[r]); }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the other 16 keys of this query live in lane ^ 32
-      const float mn = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
-      float p[16], ps = 0.f;
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;       // the other 16 keys of this query live in lane ^ 32
+      if (!__all(mx - m <= FWD_THR)) {                   // (first tile: m = -inf; a NaN score lands here too)
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] - mn); ps += p[r]; }
-      ps += __shfl_xor(ps, 32, 64);
-      l = l * alpha + ps;
-      m = mn;
+        for (int d = 0; d < F::ND; ++d)
 #pragma unroll
-      for (int d = 0; d < F::ND; ++d)
+          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+        if (!LSUM) l *= alpha;
+        m = mn;
+      }
+      float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+      for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -m));
+      if (!LSUM) {
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps += p[r];
+        ps += __shfl_xor(ps, 32, 64);
+        l += ps;
+      }
       bf16x8 pb[2];
       pack_b<FL>(p, pb);
 #pragma unroll
@@ -251,10 +268,16 @@ __global__ __launch_bounds__((FA<D, W>::NT)) void attn_fwd_kernel(FusedArgs a, b
           acc[d] = MFMA(lds_tr_frag(sV, F::LDR, kb * 32 + ks * 16, d * 32, lane), pb[ks], acc[d]);
     }
   }
+  if (LSUM) {                                            // column D of the output tile: register (D % 32 / 8) * 4 of tile D / 32 in the lanes with lhi == 0
+    static_assert(!LSUM || (D % 8 == 0 && (D % 32) / 8 * 4 < 16), "ones column of V outside the accumulator layout");
+    const float lv = acc[D / 32][(D % 32) / 8 * 4];
+    const float lo = __shfl_xor(lv, 32, 64);             // by ALL lanes: a shuffle under `lhi != 0` would read its (inactive) source lanes as 0
+    l = lhi == 0 ? lv : lo;
+  }
   const float il = 1.f / l;
   if (lhi == 0 && live) {
     float* st = stats_out + (((long)b * a.H + h) * a.L + q) * 2;
-    st[0] = m * 0.69314718055994531f;                     // natural-log units: max of the scaled scores
+    st[0] = m * 0.69314718055994531f;                     // natural-log units: the (stale) max the probabilities are taken against
     st[1] = il;
   }
   bf16* Op = O + b * (long)a.L * a.Co + (long)q * a.Co + h * D;
