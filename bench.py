@@ -266,19 +266,20 @@ def strong_leg(a, dev, dtype, dist, pdist, rank, world):
 
 
 def unet_forward_leg(a, dev, dtype, dname, t, ctx, time_cpu):
-    """Full SD-1.5 U-Net forwards (eps prediction) at B = 1 / 2 / 5 through dpb_forward (no stash), forwards/s and fraction of the MFMA peak."""
+    """Full SD-1.5 U-Net forwards (eps prediction) at B = 1 / 2 / 5 / 20 through dpb_forward (no stash), forwards/s and fraction of the MFMA peak
+    (1: DDIM inversion / forward, 2: one x-space-guidance step, 5: the reference's decode chunk, 20: the CLI's decode of all edited latents in one call)."""
     from diffusion_pullback_amd import PullbackUNet
     from diffusion_pullback_amd import configs as cf
     cfg = cf.SD15
     tw = time.perf_counter()
     params = sd_params("sd15", cfg, None, cf.Spectrum())
-    net = PullbackUNet("sd", cfg, params, dtype=dtype, device=dev, max_batch=5, max_rank=5, upto=None, verbose=False)
+    net = PullbackUNet("sd", cfg, params, dtype=dtype, device=dev, max_batch=20, max_rank=5, upto=None, verbose=False)
     build_s = time.perf_counter() - tw
     eng = net.engine
     g = torch.Generator().manual_seed(5)
     out = {"model": "SD-v1.5 UNet2DConditionModel, 859.5 M parameters, z[B,4,64,64], ctx[B,77,768], t=696.27, eps output", "dtype": dname,
            "mode": "dpb_forward: forward only, no tangent / adjoint stash", "engine_build_s": round(build_s, 1), "batches": {}}
-    for B in (1, 2, 5):
+    for B in (1, 2, 5, 20):
         z = torch.randn(B, 4, 64, 64, generator=g).to(dev)
         c = ctx.to(dev).expand(B, -1, -1).contiguous()
         for _ in range(3):
@@ -290,17 +291,19 @@ def unet_forward_leg(a, dev, dtype, dname, t, ctx, time_cpu):
             e_ = eng.forward(z, t, c, "eps")
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / n
-        # the same forward WITH the stash (dpb_primal + read), what the loop paid before dpb_forward existed
-        for _ in range(2):
-            eng.primal(z, t, c, "eps"); eng.read("eps")
-        torch.cuda.synchronize(dev); t1 = time.perf_counter()
-        for _ in range(n):
-            eng.primal(z, t, c, "eps"); eng.read("eps")
-        torch.cuda.synchronize(dev)
-        dp = (time.perf_counter() - t1) / n
+        # the same forward WITH the stash (dpb_primal + read), what the loop paid before dpb_forward existed (not at B = 20: the loop never stashed there)
+        dp = float("nan")
+        if B <= 5:
+            for _ in range(2):
+                eng.primal(z, t, c, "eps"); eng.read("eps")
+            torch.cuda.synchronize(dev); t1 = time.perf_counter()
+            for _ in range(n):
+                eng.primal(z, t, c, "eps"); eng.read("eps")
+            torch.cuda.synchronize(dev)
+            dp = (time.perf_counter() - t1) / n
         out["batches"][str(B)] = {"ms_per_forward": 1e3 * dt, "forwards_per_s": 1.0 / dt, "samples_per_s": B / dt, "tflops": fl / dt / 1e12,
                                   "frac_of_mfma_peak": fl / dt / 1e12 / PEAK[dname], "flops_per_forward": fl, "launches": eng.stats()[0],
-                                  "ms_per_forward_with_stash": 1e3 * dp, "finite": bool(torch.isfinite(e_).all())}
+                                  "ms_per_forward_with_stash": (1e3 * dp if dp == dp else None), "finite": bool(torch.isfinite(e_).all())}
     out["x_space_guidance_steps_per_s"] = out["batches"]["2"]["forwards_per_s"]
     out["reference_note"] = ("reference Colab log (T4, SD-2.1-base fp32): 2.13 it/s for x-space guidance = one batch-2 U-Net forward + axpy per step "
                              "(example-code.ipynb:146-164; src/modules/edit.py:484-502) -- context, not a same-node comparison")

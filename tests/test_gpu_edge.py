@@ -264,6 +264,42 @@ def test_short_sequence_fused_attention_matches_the_materialised_path(dtype, mon
     assert n_fused < n_mat, (n_fused, n_mat)                              # launches of the last pass (the adjoint)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_flash_forward_deferred_rescale_under_peaked_scores(dtype, monkeypatch):
+    """attn_fwd_kernel keeps a stale running max until a query of the wave outgrows it by 2^4 (round 6).  Here the q / k projections of a d = 40,
+    L = 1024 layer (eight 128-key stages) are scaled up so that the scores spread over tens of log2 units: rows whose maximum sits in a late stage take
+    the rescale branch long after the first stage, others never.  Primal, tangent and adjoint (which consume the (stale max, 1 / l) statistics) against
+    the materialised path, whose softmax is a plain three-pass one."""
+    from diffusion_pullback_amd import PullbackUNet
+    from oracle import unet_sd
+    cfg = unet_sd.SDConfig(block_out_channels=(320,), layers_per_block=1, down_attn=(True,), up_attn=(True,), heads=(8,), cross_dim=768,
+                           sample_size=32, ctx_len=77)                    # 32x32 tokens = 1024, 8 heads of 40
+    p = unet_sd.init_params(cfg, seed=7)
+    for n in list(p):
+        if n.endswith("attn1.to_q.weight") or n.endswith("attn1.to_k.weight"):
+            p[n] = p[n] * 5.0                                             # scores x 25
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(1, 4, 32, 32, generator=g); ctx = torch.randn(1, 77, 768, generator=g)
+    tap = ("mid", 0)
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-3
+    nets = {}
+    for name, min_l in (("materialised", "4096"), ("fused", "256")):
+        monkeypatch.setenv("DPB_FUSED_ATTN_MIN_L", min_l)
+        nets[name] = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=1, max_rank=5, upto=tap, verbose=False)
+    monkeypatch.delenv("DPB_FUSED_ATTN_MIN_L")
+    V = torch.randn(5, 4 * 32 * 32, generator=g)
+    U = torch.randn(5, nets["fused"].engine.tap_numel(tap), generator=g)
+    out = {}
+    for name, net in nets.items():
+        e = net.engine
+        e.primal(z, 696.2727, ctx, tap)
+        out[name] = (e.read(tap).clone(), e.jvp(tap, V).clone(), e.vjp(tap, U).clone())
+    errs = [rel(b, a) for a, b in zip(out["materialised"], out["fused"])]
+    assert all(torch.isfinite(b).all() for b in out["fused"]), errs
+    assert max(errs) < tol, errs
+    assert nets["fused"].engine.stats()[0] < nets["materialised"].engine.stats()[0]          # the fused kernels did run
+
+
 def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
     """Split-K products whose consumer is a one-launch GroupNorm or a LayerNorm leave their fp32 slabs to that kernel (no splitk_reduce_kernel launch,
     no 16-bit round trip of the tensor unless another op reads it).  The consumer adds the slabs in slab order, adds the residual and rounds exactly
