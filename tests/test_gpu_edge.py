@@ -267,37 +267,46 @@ def test_short_sequence_fused_attention_matches_the_materialised_path(dtype, mon
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_flash_forward_deferred_rescale_under_peaked_scores(dtype, monkeypatch):
     """attn_fwd_kernel keeps a stale running max until a query of the wave outgrows it by 2^4 (round 6).  Here the q / k projections of a d = 40,
-    L = 1024 layer (eight 128-key stages) are scaled up so that the scores spread over tens of log2 units: rows whose maximum sits in a late stage take
+    L = 1024 layer (eight 128-key stages) are scaled up so that the scores spread over many log2 units: rows whose maximum sits in a late stage take
     the rescale branch long after the first stage, others never.  Primal, tangent and adjoint (which consume the (stale max, 1 / l) statistics) against
-    the materialised path, whose softmax is a plain three-pass one."""
+    the fp32 CPU oracle; the yardstick is the materialised path (three-pass softmax over scores stored in 16 bits, which is what limits IT at this score
+    range): the fused kernels, whose scores stay in fp32 registers, have to be at least as close to the oracle."""
     from diffusion_pullback_amd import PullbackUNet
     from oracle import unet_sd
+    from _util import oracle_jvp, oracle_vjp
     cfg = unet_sd.SDConfig(block_out_channels=(320,), layers_per_block=1, down_attn=(True,), up_attn=(True,), heads=(8,), cross_dim=768,
                            sample_size=32, ctx_len=77)                    # 32x32 tokens = 1024, 8 heads of 40
     p = unet_sd.init_params(cfg, seed=7)
     for n in list(p):
         if n.endswith("attn1.to_q.weight") or n.endswith("attn1.to_k.weight"):
-            p[n] = p[n] * 5.0                                             # scores x 25
+            p[n] = p[n] * 3.0                                             # scores x 9
     g = torch.Generator().manual_seed(8)
     z = torch.randn(1, 4, 32, 32, generator=g); ctx = torch.randn(1, 77, 768, generator=g)
     tap = ("mid", 0)
-    tol = 3e-2 if dtype == torch.bfloat16 else 5e-3
-    nets = {}
+    f = lambda a: unet_sd.forward(p, cfg, a, torch.tensor(696.2727), ctx, stop=tap)
+    V = torch.randn(2, 4 * 32 * 32, generator=g)
+    with torch.no_grad():
+        h_ref = f(z)
+    U = torch.randn(2, h_ref.numel(), generator=g)
+    ref = (h_ref.reshape(-1), oracle_jvp(f, z, V), oracle_vjp(f, z, U))
+    errs = {}
+    launches = {}
     for name, min_l in (("materialised", "4096"), ("fused", "256")):
         monkeypatch.setenv("DPB_FUSED_ATTN_MIN_L", min_l)
-        nets[name] = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=1, max_rank=5, upto=tap, verbose=False)
-    monkeypatch.delenv("DPB_FUSED_ATTN_MIN_L")
-    V = torch.randn(5, 4 * 32 * 32, generator=g)
-    U = torch.randn(5, nets["fused"].engine.tap_numel(tap), generator=g)
-    out = {}
-    for name, net in nets.items():
+        net = PullbackUNet("sd", cfg, p, dtype=dtype, device="cuda:0", max_batch=1, max_rank=2, upto=tap, verbose=False)
         e = net.engine
         e.primal(z, 696.2727, ctx, tap)
-        out[name] = (e.read(tap).clone(), e.jvp(tap, V).clone(), e.vjp(tap, U).clone())
-    errs = [rel(b, a) for a, b in zip(out["materialised"], out["fused"])]
-    assert all(torch.isfinite(b).all() for b in out["fused"]), errs
-    assert max(errs) < tol, errs
-    assert nets["fused"].engine.stats()[0] < nets["materialised"].engine.stats()[0]          # the fused kernels did run
+        out = (e.read(tap).reshape(-1).cpu(), e.jvp(tap, V.cuda()).cpu(), e.vjp(tap, U.cuda()).cpu())
+        assert all(torch.isfinite(o).all() for o in out), name
+        errs[name] = [rel(o, r) for o, r in zip(out, ref)]
+        launches[name] = e.stats()[0]
+        del net, e
+    monkeypatch.delenv("DPB_FUSED_ATTN_MIN_L")
+    print("relative errors vs the fp32 oracle (primal, tangent, adjoint):", errs)
+    assert launches["fused"] < launches["materialised"], launches                  # the fused kernels did run
+    for ef, em in zip(errs["fused"], errs["materialised"]):
+        assert ef <= 1.25 * em + 2e-3, errs
+    assert max(errs["fused"]) < (0.15 if dtype == torch.bfloat16 else 0.03), errs     # and stay sane in absolute terms at a 9x score range
 
 
 def test_deferred_split_k_reduction_is_bitwise_the_separate_reduce_kernel():
