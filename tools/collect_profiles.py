@@ -93,7 +93,8 @@ def main():
             kernels["gemm_dma_kernel<128,128,3> / <256,128,3>"] = {"launches": n, "fetch_kb_per_launch": sum(x["fetch_kb_per_launch"] * x["launches"] for x in parts) / n,
                                                                    "write_kb_per_launch": sum(x["write_kb_per_launch"] * x["launches"] for x in parts) / n}
         whole = sum((2.0 * e["fetch_kb_per_launch"] + e.get("write_kb_per_launch", 0.0)) * 1024.0 * e["launches"]
-                    for e in json.load(open(pj))["kernels"].values() if "fetch_kb_per_launch" in e) / PMC_ITERS
+                    for kn, e in json.load(open(pj))["kernels"].items()
+                    if "fetch_kb_per_launch" in e and not kn.startswith("at::")) / PMC_ITERS     # (torch's kernels = the engine build's weight packing, once per process)
         json.dump({"_whole_step_hbm_bytes": whole,   # every kernel of the PMC run, per power iteration (bench.py: roofline.whole_step_hbm_frac)
                    "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 12 --warmup 0 "
                               "--no-cpu-baseline --no-roofline (SD-1.5 mid, k=5, bf16, 1 sample); tools/pmc_mfma.sh",
