@@ -369,6 +369,56 @@ def test_orth_scratch_contract_follows_the_block_layout():
     assert all(f(k, n) <= f(k, 2 * n) for k in (1, 5, 50) for n in (64, 1000, 16384, 100000))
 
 
+def test_flash_forward_isa_keeps_the_rescale_and_the_row_sum_off_the_hot_path(tmp_path):
+    """attn_fwd_kernel (csrc/attn_fused.hip, round 6) was VALU-bound 2-3x over its MFMAs; what took it to 1.67x is structural and a compiler or an edit can
+    silently undo it: (i) the accumulator rescale (32 multiplies per 32 keys) must sit behind a scalar branch, not be if-converted back into the straight-line
+    code of the MFMAs; (ii) at d = 40 the row sum comes out of the P V product (ones column), so the MFMA segments carry no chain of adds; (iii) the shuffle
+    that hands l to the other half-wave is executed by ALL lanes -- under an exec mask it reads its inactive source lanes as 0 (l = 0 -> NaN: the first
+    build of the round, caught only on the GPU).  Read off the gfx950 ISA hipcc emits here."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    out = tmp_path / "attn_fused.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
+                        os.path.join(root, "diffusion_pullback_amd", "csrc", "attn_fused.hip"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    kernels = re.split(r"^(_ZN3dpb15attn_fwd_kernelILi40ELi[01]ELi8EEEvNS_9FusedArgsEPNS_4bf16EPf):", text, flags=re.M)[1:]
+    assert len(kernels) == 2 * 2, "expected attn_fwd_kernel<40, 0 | 1, 8>"
+    for name, body in zip(kernels[0::2], kernels[1::2]):
+        body = body.split(".Lfunc_end")[0]
+        assert "scratch_" not in body, name
+        ins = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        ins = [i for i in ins if i and not (i.startswith(".") and not i.endswith(":"))]
+        segs, cur, lead = [], [], ""                        # straight-line segments; `lead` = what ended the previous one (a label or a branch)
+        for i in ins:
+            if i.endswith(":") or i.startswith("s_cbranch") or i.startswith("s_branch"):
+                segs.append((lead, cur)); cur, lead = [], i
+            else:
+                cur.append(i)
+        segs.append((lead, cur))
+        n = lambda seg, *pre: sum(1 for i in seg if i.startswith(pre))
+        hot = [seg for _, seg in segs if n(seg, "v_mfma_")]
+        assert len(hot) >= 4 and sum(n(seg, "v_mfma_") for seg in hot) == 4 * 7, name          # 3 score + 4 output MFMAs per 32 keys, four blocks per stage
+        for seg in hot:
+            assert n(seg, "v_pk_mul_f32", "v_mul_f32") <= 2, (name, "accumulator rescale inside an MFMA segment", n(seg, "v_pk_mul_f32", "v_mul_f32"))
+            assert n(seg, "v_add_f32", "v_pk_add_f32") <= 2, (name, "row-sum adds inside an MFMA segment")
+        rescale = [(lead, seg) for lead, seg in segs if n(seg, "v_pk_mul_f32") + n(seg, "v_mul_f32") // 2 >= 12 and not n(seg, "v_mfma_")]
+        assert len(rescale) >= 4, (name, len(rescale))
+        assert all(lead.startswith("s_cbranch_scc") or lead.startswith("s_cbranch_vcc") for lead, _ in rescale), (name, [lead for lead, _ in rescale])
+        assert sum(n(seg, "v_exp_f32") for seg in hot) == 4 * 16, name                             # one exp per score; the four alpha exps live in the rescale segments
+        last_mfma = max(k for k, (_, seg) in enumerate(segs) if n(seg, "v_mfma_"))
+        tail = [i for _, seg in segs[last_mfma:] for i in seg]
+        shf = [k for k, i in enumerate(tail) if i.startswith("ds_bpermute_b32") or "permlane32_swap" in i or "row_" in i and "dpp" in i]
+        assert shf, (name, "the half-wave exchange of l was not found behind the loop")
+        masked = 0
+        for i in tail[:shf[-1]]:
+            masked += i.startswith("s_and_saveexec_b64") - (i.startswith("s_or_b64 exec"))
+        assert masked <= 0, (name, "the exchange of l runs under an exec mask")
+
+
 def test_measurement_scripts_compile():
     """tools/*.py and bench.py are not imported by any test (they need a GPU box): at least their syntax is checked here."""
     import glob, os, py_compile
